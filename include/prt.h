@@ -1,0 +1,198 @@
+/*
+ * prt.h — C ABI of libprt_hip.so, the MI355X (gfx950) path-tracing hot path.
+ *
+ * This is the drop-in boundary for the reference's per-pixel / per-sample hot path
+ *     Camera::Render -> RayColor -> BVHNode::Hit -> Triangle::Hit / AABB::Hit
+ * (reference: Source/Camera.cpp:21-204, Source/BVH.cpp:51-61, Source/Triangle.cpp:54-83,
+ *  Source/AABB.cpp:38-64).  The reference has no FFI layer of its own; the
+ * entry points below are what a binding for that path would call:
+ *
+ *   prt_scene_create      replaces the object graph main.cpp:36-45 builds
+ *                         (Mesh/Triangle ctor precompute Source/Triangle.cpp:11-53,
+ *                          two-level BVHNode build Source/BVH.cpp:6-49, lights list main.cpp:40-45)
+ *   prt_trace_closest     replaces world.Hit(ray, Interval(tmin,tmax), record)
+ *                         (Source/HittableList.h:26-39 -> Source/BVH.cpp:51-61)
+ *   prt_render            replaces Camera::Render(world, lights)      (Source/Camera.cpp:21-73)
+ *   prt_render_device     same, framebuffer left in device memory for an RCCL reduce
+ *   prt_sample_lights     replaces lights.Sample(origin, record, pdf) (Source/HittableList.h:44-59,
+ *                          Source/BVH.cpp:62-67,86-100, Source/Triangle.cpp:84-93) — test hook
+ *   prt_get_counters      rays / node fetches / triangle tests / kernel ms of the last call
+ *
+ * Conventions: every function returns 0 on success or a negative PRT_E_* code and never throws;
+ * prt_last_error() returns a thread-local message for the last failure.  All input buffers are
+ * owned by the caller and may be freed as soon as the call returns.  Handles are opaque.  One
+ * host thread per device; calls on different handles are independent.  No CPU fallback exists:
+ * without a HIP device every compute entry point fails with PRT_E_NO_DEVICE.
+ */
+#ifndef PRT_H
+#define PRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRT_ABI_VERSION 1
+
+/* error codes */
+#define PRT_OK 0
+#define PRT_E_INVALID (-1)    /* bad argument / inconsistent scene description */
+#define PRT_E_NO_DEVICE (-2)  /* no HIP device visible */
+#define PRT_E_HIP (-3)        /* a HIP runtime call failed (message has the HIP error string) */
+#define PRT_E_OOM (-4)        /* host or device allocation failed */
+#define PRT_E_LIMIT (-5)      /* scene exceeds a compiled-in limit (BVH depth, leaf encoding) */
+
+/* Material kinds — reference enum MaterialType, Source/Material.h:48-51 */
+#define PRT_MAT_LAMBERTIAN 0    /* Source/Material.h:101-155 */
+#define PRT_MAT_PHONG 1         /* PhoneReflectance, Source/Material.h:172-330 */
+#define PRT_MAT_MIRROR 2        /* PerfectMirror, Source/Material.h:332-366 */
+#define PRT_MAT_COOKTORRANCE 3  /* Source/Material.h:368-521 */
+#define PRT_MAT_DIFFUSE_LIGHT 4 /* Source/Material.h:157-170 */
+#define PRT_MAT_DEBUG 5         /* Source/Material.h:523-535 (emits its albedo) */
+#define PRT_MAT_EMPTY 6         /* Source/Material.h:537-540 */
+
+typedef struct PrtMaterial {
+    int32_t type;      /* PRT_MAT_* */
+    int32_t texture;   /* index into PrtSceneDesc.textures for the Kd map, or -1 (SolidColor) */
+    double kd[3];      /* Lambertian albedo / Phong Kd / Debug albedo */
+    double ks[3];      /* Phong Ks (ignored when texture >= 0: reference stores mapKd in both, Material.h:178-181) */
+    double ns;         /* Phong exponent */
+    double emission[3];/* DiffuseLight radiance (XML <light radiance>, Source/Model.cpp:332-360) */
+    double eta[3];     /* CookTorrance conductor eta */
+    double k[3];       /* CookTorrance conductor k */
+    double alpha_x, alpha_y; /* CookTorrance roughness */
+} PrtMaterial;
+
+/* 8-bit interleaved texels exactly as stbi_load returns them (Source/Texture.cpp:10-21). */
+typedef struct PrtTexture {
+    int32_t width, height, channels, reserved;
+    const uint8_t* data; /* width*height*channels bytes; NULL => reference's "missing" colour (0,1,1) */
+} PrtTexture;
+
+/*
+ * Scene = list of meshes; a mesh = contiguous triangle range + one material
+ * (reference: Mesh, Source/Triangle.h:36-43; one material per shape, Source/Model.cpp:118).
+ * Triangle order inside a mesh and mesh order are significant: they are the input order of the
+ * reference's std::sort-based light-tree build, which fixes the NEE light CDF order.
+ */
+typedef struct PrtSceneDesc {
+    uint64_t n_tris;
+    const double* vertices;  /* [n_tris][3 verts][xyz] */
+    const double* normals;   /* [n_tris][3][xyz] vertex normals (degenerate-face fallback only) or NULL */
+    const double* texcoords; /* [n_tris][3][uv] or NULL (all zero) */
+    uint32_t n_meshes;
+    uint32_t n_materials;
+    const uint64_t* mesh_first_tri; /* [n_meshes+1], ascending, last == n_tris */
+    const int32_t* mesh_material;   /* [n_meshes] index into materials */
+    const PrtMaterial* materials;
+    uint32_t n_textures;
+    uint32_t reserved;
+    const PrtTexture* textures;
+} PrtSceneDesc;
+
+/* Public camera fields of the reference, Source/Camera.h:14-24. */
+typedef struct PrtCamera {
+    int32_t width, height;
+    double fovy; /* degrees */
+    double eye[3], look_at[3], up[3];
+} PrtCamera;
+
+#define PRT_PRECISION_F64 0 /* reference arithmetic (glm::dvec3 everywhere) */
+
+typedef struct PrtRenderParams {
+    int32_t spp;           /* Camera::samplesPerPixel */
+    int32_t max_depth;     /* Camera::maxDepth (maxDepth+1 path vertices, Camera.cpp:121) */
+    double russian_roulette; /* Camera::russianRoulette */
+    int32_t sample_lights; /* Camera::bSampleLights */
+    int32_t precision;     /* PRT_PRECISION_* */
+    double background[3];  /* Camera::background */
+    uint64_t seed;         /* per-sample RNG key = (seed, j*W+i, s) */
+    int32_t tile_size;     /* multi-GPU tile edge in pixels (0 => 32) */
+    int32_t rank, nranks;  /* this device renders tiles k with k % nranks == rank; others stay 0 */
+    int32_t sample_chunks; /* 0 => auto; partial sums per pixel are combined in fixed order */
+} PrtRenderParams;
+
+/* One ray of a batch: world.Hit(Ray(o,d), Interval(tmin,tmax)). */
+typedef struct PrtRay {
+    double o[3];
+    double tmin;
+    double d[3];
+    double tmax;
+} PrtRay;
+
+/* HitRecord subset that identifies the hit (Source/Hittable.h:17-28). */
+typedef struct PrtHit {
+    double t;      /* HitRecord::time; +inf on miss */
+    double alpha;  /* barycentric of v1 (Triangle.cpp:69) */
+    double beta;   /* barycentric of v2 (Triangle.cpp:70) */
+    int32_t prim;  /* triangle index in PrtSceneDesc order, -1 on miss */
+    int32_t front; /* HitRecord::bFrontFace */
+} PrtHit;
+
+/* lights.Sample() result (test hook). */
+typedef struct PrtLightSample {
+    double position[3];
+    double normal[3]; /* face-forwarded against (p - origin), Triangle.cpp:89-90 */
+    double pdf;       /* 1 / total light area */
+    int32_t prim;
+    int32_t front;
+} PrtLightSample;
+
+typedef struct PrtCounters {
+    uint64_t rays_closest;  /* camera + continuation traversals */
+    uint64_t rays_shadow;   /* NEE visibility traversals */
+    uint64_t node_fetches;  /* 128-byte BVH node records read (counting runs only) */
+    uint64_t tri_tests;     /* 128-byte triangle records tested (counting runs only) */
+    uint64_t samples;       /* camera samples started */
+    double kernel_ms;       /* hipEvent time of the dominant kernel of the last call */
+    uint64_t bvh_nodes;     /* static: nodes in the flattened tree */
+    uint64_t bvh_depth;     /* static: max depth */
+} PrtCounters;
+
+typedef struct PrtScene PrtScene;
+
+int prt_abi_version(void);
+const char* prt_last_error(void);
+int prt_device_count(int* n);
+
+int prt_scene_create(const PrtSceneDesc* desc, PrtScene** out);
+void prt_scene_destroy(PrtScene* scene);
+/* Build + flatten the BVH on the host and upload SoA nodes / triangles / materials / light tree. */
+int prt_scene_upload(PrtScene* scene, int device);
+
+/* Number of light triangles and their order in the reference's area-CDF descent (BVH.cpp:86-100). */
+int prt_scene_light_count(const PrtScene* scene, uint64_t* n);
+int prt_scene_light_order(const PrtScene* scene, int32_t* prims, uint64_t cap);
+
+/* K1: closest hit for a batch of host rays; with count_work != 0 the counting instantiation runs. */
+int prt_trace_closest(PrtScene* scene, const PrtRay* rays, size_t n, PrtHit* hits, int count_work);
+/* K1 on device-resident buffers (d_rays/d_hits are device pointers); stream may be NULL. */
+int prt_trace_closest_device(PrtScene* scene, const void* d_rays, size_t n, void* d_hits,
+                             int count_work, void* hip_stream);
+
+/* NEE point selection for (pixel, sample) keys 0..n-1 of `seed` from given origins (test hook). */
+int prt_sample_lights(PrtScene* scene, const double* origins, size_t n, uint64_t seed,
+                      PrtLightSample* out);
+
+/*
+ * K3+K5: render one frame.  rgb_f64 / rgb_f32 are W*H*3 row-major host buffers (either may be
+ * NULL).  Pixels of tiles owned by other ranks are written as 0 so a sum over ranks is exact.
+ */
+int prt_render(PrtScene* scene, const PrtCamera* cam, const PrtRenderParams* params,
+               double* rgb_f64, float* rgb_f32);
+/* Same, outputs are device pointers on the scene's device; asynchronous on hip_stream. */
+int prt_render_device(PrtScene* scene, const PrtCamera* cam, const PrtRenderParams* params,
+                      void* d_rgb_f64, void* d_rgb_f32, int count_work, void* hip_stream);
+
+int prt_get_counters(PrtScene* scene, PrtCounters* out);
+
+/* K5 "next" row: NaN scrub + linear->sRGB + clamp -> 8-bit RGB (Camera.cpp:206-221,279-301). */
+int prt_tonemap_srgb8(PrtScene* scene, const void* d_rgb_f32, int width, int height,
+                      void* d_rgb_u8, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRT_H */

@@ -1,0 +1,138 @@
+/*
+ * oracle.h — C ABI of the CPU oracle (liboracle.so).
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under pooraytracer_amd/ or include/ may include, link or
+ * load this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the
+ * checker / reported baseline — never as the thing shipped or measured as the product.
+ *
+ * PARITY UNPINNED: the reference (Zoz4/Pooraytracer) has no tests, golden vectors or fixtures for
+ * this path, its third-party headers (glm, spdlog, stb, tinyxml2, tinyobjloader) are
+ * absent so it is unbuildable here without stand-in headers (which the build rules forbid), and it
+ * is C++ so it cannot be imported.  This oracle is therefore a line-by-line CPU restatement of the
+ * reference algorithm (each function cites the reference file:line it follows), pinned only by
+ * hand-derived known-answer tests and its own committed fixtures in tests/golden/.
+ *
+ * The struct layouts deliberately equal those of include/prt.h so a test can hand the same
+ * buffers to both libraries; they are re-declared here so the oracle has no product dependency.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OrcMaterial {
+    int32_t type;
+    int32_t texture;
+    double kd[3];
+    double ks[3];
+    double ns;
+    double emission[3];
+    double eta[3];
+    double k[3];
+    double alpha_x, alpha_y;
+} OrcMaterial;
+
+typedef struct OrcTexture {
+    int32_t width, height, channels, reserved;
+    const uint8_t* data;
+} OrcTexture;
+
+typedef struct OrcSceneDesc {
+    uint64_t n_tris;
+    const double* vertices;
+    const double* normals;
+    const double* texcoords;
+    uint32_t n_meshes;
+    uint32_t n_materials;
+    const uint64_t* mesh_first_tri;
+    const int32_t* mesh_material;
+    const OrcMaterial* materials;
+    uint32_t n_textures;
+    uint32_t reserved;
+    const OrcTexture* textures;
+} OrcSceneDesc;
+
+typedef struct OrcCamera {
+    int32_t width, height;
+    double fovy;
+    double eye[3], look_at[3], up[3];
+} OrcCamera;
+
+typedef struct OrcRenderParams {
+    int32_t spp;
+    int32_t max_depth;
+    double russian_roulette;
+    int32_t sample_lights;
+    int32_t precision;
+    double background[3];
+    uint64_t seed;
+    int32_t tile_size;
+    int32_t rank, nranks;
+    int32_t sample_chunks;
+} OrcRenderParams;
+
+typedef struct OrcRay {
+    double o[3];
+    double tmin;
+    double d[3];
+    double tmax;
+} OrcRay;
+
+typedef struct OrcHit {
+    double t;
+    double alpha;
+    double beta;
+    int32_t prim;
+    int32_t front;
+} OrcHit;
+
+typedef struct OrcLightSample {
+    double position[3];
+    double normal[3];
+    double pdf;
+    int32_t prim;
+    int32_t front;
+} OrcLightSample;
+
+typedef struct OrcCounters {
+    uint64_t rays_closest; /* unique camera + continuation traversals (peek re-trace not counted) */
+    uint64_t rays_shadow;
+    uint64_t hit_calls;    /* world.Hit calls actually executed */
+    uint64_t samples;
+} OrcCounters;
+
+typedef struct OrcScene OrcScene;
+
+OrcScene* orc_scene_create(const OrcSceneDesc* desc);
+void orc_scene_destroy(OrcScene*);
+uint64_t orc_light_count(const OrcScene*);
+void orc_light_order(const OrcScene*, int32_t* prims);
+
+/* world.Hit(ray, Interval(tmin,tmax), record) for each ray. */
+void orc_trace_closest(const OrcScene*, const OrcRay* rays, size_t n, OrcHit* hits);
+/* lights.Sample(origin_i) with the stream keyed (seed, i, 0). */
+void orc_sample_lights(const OrcScene*, const double* origins, size_t n, uint64_t seed,
+                       OrcLightSample* out);
+/* first `n` uniforms of the stream keyed (seed, pixel, sample). */
+void orc_rng_stream(uint64_t seed, uint64_t pixel, uint64_t sample, size_t n, double* out);
+
+/*
+ * Camera::Render with per-sample keyed RNG.  rows [y0,y1) only (others untouched); nthreads row-
+ * interleaved workers; reuse_peek != 0 hands the peek hit (Camera.cpp:187) to the recursive call
+ * instead of re-tracing the identical ray (output identical, asserted by tests).
+ */
+void orc_render(const OrcScene*, const OrcCamera*, const OrcRenderParams*, double* rgb_f64,
+                int y0, int y1, int nthreads, int reuse_peek, OrcCounters* counters);
+/* per-sample radiance of selected pixels: out[n_pixels][spp][3]. */
+void orc_render_samples(const OrcScene*, const OrcCamera*, const OrcRenderParams*,
+                        const int32_t* pixel_xy, size_t n_pixels, double* out);
+/* camera rays (origin, unnormalised direction) for all pixels: out[H][W][6] (Camera.cpp:75-117). */
+void orc_camera_rays(const OrcCamera*, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

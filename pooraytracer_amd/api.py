@@ -1,0 +1,143 @@
+"""Python binding of libprt_hip.so (ctypes over the C ABI in include/prt.h).
+
+This is test / benchmark plumbing: numpy (or torch device pointers) in, numpy out.  All compute
+happens in the HIP kernels; there is no Python or CPU fallback — if the library or a GPU is missing
+the calls raise PrtError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libprt_hip.so")
+_lib = None
+
+
+class PrtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libprt_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """dlopen the in-tree libprt_hip.so (build it first with pooraytracer_amd.build.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise PrtError(-100, f"{_LIB_PATH} not built; run `python -m pooraytracer_amd.build` (needs hipcc)")
+    L = C.CDLL(_LIB_PATH)
+    vp, sz, i32, u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
+    L.prt_abi_version.restype = C.c_int
+    L.prt_last_error.restype = C.c_char_p
+    L.prt_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.prt_scene_create.argtypes = [vp, C.POINTER(vp)]
+    L.prt_scene_destroy.argtypes = [vp]
+    L.prt_scene_destroy.restype = None
+    L.prt_scene_upload.argtypes = [vp, i32]
+    L.prt_scene_light_count.argtypes = [vp, C.POINTER(u64)]
+    L.prt_scene_light_order.argtypes = [vp, vp, u64]
+    L.prt_trace_closest.argtypes = [vp, vp, sz, vp, i32]
+    L.prt_trace_closest_device.argtypes = [vp, vp, sz, vp, i32, vp]
+    L.prt_sample_lights.argtypes = [vp, vp, sz, u64, vp]
+    L.prt_render.argtypes = [vp, vp, vp, vp, vp]
+    L.prt_render_device.argtypes = [vp, vp, vp, vp, vp, i32, vp]
+    L.prt_get_counters.argtypes = [vp, vp]
+    L.prt_tonemap_srgb8.argtypes = [vp, vp, i32, i32, vp, vp]
+    if L.prt_abi_version() != _abi.PRT_ABI_VERSION:
+        raise PrtError(-101, "ABI version mismatch between _abi.py and libprt_hip.so")
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise PrtError(rc, load().prt_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load().prt_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+class Scene:
+    """A scene handle: host-side preparation at construction, `upload(device)` before any compute."""
+
+    def __init__(self, scene_data):
+        self.data = scene_data
+        L = load()
+        desc, keep = _abi.marshal_scene(scene_data)
+        h = C.c_void_p()
+        _check(L.prt_scene_create(C.byref(desc), C.byref(h)))
+        del keep  # the library copies everything it needs during create
+        self._h = h
+        self.device = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().prt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, device=0):
+        _check(load().prt_scene_upload(self._h, device))
+        self.device = device
+        return self
+
+    def light_order(self):
+        n = C.c_uint64(0)
+        _check(load().prt_scene_light_count(self._h, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.int32)
+        _check(load().prt_scene_light_order(self._h, out.ctypes.data, n.value))
+        return out
+
+    def trace_closest(self, rays, count_work=False):
+        rays = np.ascontiguousarray(rays, dtype=_abi.RAY_DTYPE)
+        hits = np.zeros(rays.shape[0], dtype=_abi.HIT_DTYPE)
+        _check(load().prt_trace_closest(self._h, rays.ctypes.data, rays.shape[0], hits.ctypes.data, int(count_work)))
+        return hits
+
+    def trace_closest_device(self, d_rays_ptr, n, d_hits_ptr, count_work=False, stream=None):
+        _check(load().prt_trace_closest_device(self._h, d_rays_ptr, n, d_hits_ptr, int(count_work), stream))
+
+    def sample_lights(self, origins, seed=1):
+        origins = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros(origins.shape[0], dtype=_abi.LIGHT_SAMPLE_DTYPE)
+        _check(load().prt_sample_lights(self._h, origins.ctypes.data, origins.shape[0], seed, out.ctypes.data))
+        return out
+
+    def render(self, camera=None, f32=False, **kw):
+        """Render one frame to host memory.  Returns (H,W,3) float64 (and float32 if f32=True)."""
+        cam = camera or self.data.camera
+        c, p = _abi.make_camera(cam), _abi.make_params(**kw)
+        out64 = np.zeros((cam.height, cam.width, 3), dtype=np.float64)
+        out32 = np.zeros((cam.height, cam.width, 3), dtype=np.float32) if f32 else None
+        _check(load().prt_render(self._h, C.byref(c), C.byref(p), out64.ctypes.data,
+                                 out32.ctypes.data if f32 else None))
+        return (out64, out32) if f32 else out64
+
+    def render_device(self, d_f64_ptr, d_f32_ptr, camera=None, count_work=False, stream=None, **kw):
+        """Asynchronous render into device buffers (raw device pointers, e.g. torch tensor.data_ptr())."""
+        cam = camera or self.data.camera
+        c, p = _abi.make_camera(cam), _abi.make_params(**kw)
+        _check(load().prt_render_device(self._h, C.byref(c), C.byref(p), d_f64_ptr, d_f32_ptr, int(count_work), stream))
+
+    def tonemap_srgb8(self, d_f32_ptr, width, height, d_u8_ptr, stream=None):
+        _check(load().prt_tonemap_srgb8(self._h, d_f32_ptr, width, height, d_u8_ptr, stream))
+
+    def counters(self):
+        c = _abi.PrtCounters()
+        _check(load().prt_get_counters(self._h, C.byref(c)))
+        return {f: getattr(c, f) for f, _ in _abi.PrtCounters._fields_}

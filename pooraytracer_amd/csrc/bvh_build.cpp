@@ -1,0 +1,237 @@
+// bvh_build.cpp — host builder of the traversal BVH for the HIP kernels.
+//
+// The reference builds a pointer-based median-split tree with one triangle per leaf
+// (Source/BVH.cpp:7-48).  Closest-hit results do not depend on the tree (only ties do), so this
+// builder is free to produce what gfx950 traverses fastest: a binned-SAH BVH2, up to PRT_LEAF_MAX
+// triangles per leaf, flattened pre-order into 64-byte nodes that carry BOTH children's boxes
+// (one node fetch = two slab tests, two nodes per 128-byte L2 line), boxes stored as fp32 rounded
+// outward (+ a small inflation that covers the rounding of the kernel's fma slab test) so the box
+// test can only ever cull conservatively — every hit accept/reject is the fp64 triangle test.
+// Depth is bounded so the per-lane LDS stack (PRT_STACK_DEPTH entries) cannot overflow.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "prt_host.h"
+
+namespace prt {
+namespace {
+
+constexpr int kBins = 16;
+constexpr int kMaxLevels = PRT_STACK_DEPTH - 2; // inner-node levels
+constexpr float kCostTri = 1.5f, kCostNode = 1.0f;
+
+struct PrimRef {
+    float lo[3], hi[3];
+    uint32_t idx;
+};
+struct FBox {
+    float lo[3], hi[3];
+    void reset() {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::numeric_limits<float>::infinity();
+            hi[a] = -std::numeric_limits<float>::infinity();
+        }
+    }
+    void grow(const float* l, const float* h) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], l[a]);
+            hi[a] = std::max(hi[a], h[a]);
+        }
+    }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+inline float round_down(double v) {
+    float f = (float)v;
+    if ((double)f > v) f = std::nextafter(f, -std::numeric_limits<float>::infinity());
+    return f;
+}
+inline float round_up(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafter(f, std::numeric_limits<float>::infinity());
+    return f;
+}
+
+struct Builder {
+    std::vector<PrimRef> prims;
+    std::vector<DNode>& nodes;
+    uint32_t max_depth = 0;
+    explicit Builder(std::vector<DNode>& n) : nodes(n) {}
+
+    static int32_t leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
+
+    void range_box(uint32_t s, uint32_t e, FBox& b) const {
+        b.reset();
+        for (uint32_t i = s; i < e; ++i) b.grow(prims[i].lo, prims[i].hi);
+    }
+
+    // Returns the ref of the subtree over prims[s,e) and its box.  `levels` = inner levels still allowed.
+    int32_t build(uint32_t s, uint32_t e, int levels, uint32_t depth, FBox& box, bool force_inner) {
+        const uint32_t count = e - s;
+        range_box(s, e, box);
+        max_depth = std::max(max_depth, depth);
+        if (!force_inner && (count == 1 || levels == 0)) return leaf_ref(s, count);
+
+        // centroid bounds
+        float clo[3], chi[3];
+        for (int a = 0; a < 3; ++a) {
+            clo[a] = std::numeric_limits<float>::infinity();
+            chi[a] = -clo[a];
+        }
+        for (uint32_t i = s; i < e; ++i)
+            for (int a = 0; a < 3; ++a) {
+                float c = 0.5f * (prims[i].lo[a] + prims[i].hi[a]);
+                clo[a] = std::min(clo[a], c);
+                chi[a] = std::max(chi[a], c);
+            }
+
+        // binned SAH over the three axes
+        float best_cost = std::numeric_limits<float>::infinity();
+        int best_axis = -1, best_bin = -1;
+        const float parent_area = std::max(box.half_area(), 1e-30f);
+        for (int a = 0; a < 3; ++a) {
+            const float ext = chi[a] - clo[a];
+            if (!(ext > 0.f)) continue;
+            FBox bb[kBins];
+            uint32_t bc[kBins];
+            for (int b = 0; b < kBins; ++b) {
+                bb[b].reset();
+                bc[b] = 0;
+            }
+            const float k = kBins * (1.f - 1e-6f) / ext;
+            for (uint32_t i = s; i < e; ++i) {
+                float c = 0.5f * (prims[i].lo[a] + prims[i].hi[a]);
+                int b = std::min(kBins - 1, std::max(0, (int)((c - clo[a]) * k)));
+                bb[b].grow(prims[i].lo, prims[i].hi);
+                bc[b]++;
+            }
+            float right_area[kBins];
+            uint32_t right_cnt[kBins];
+            FBox acc;
+            acc.reset();
+            uint32_t n = 0;
+            for (int b = kBins - 1; b > 0; --b) {
+                if (bc[b]) acc.grow(bb[b].lo, bb[b].hi);
+                n += bc[b];
+                right_area[b] = n ? acc.half_area() : 0.f;
+                right_cnt[b] = n;
+            }
+            acc.reset();
+            n = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                if (bc[b]) acc.grow(bb[b].lo, bb[b].hi);
+                n += bc[b];
+                const uint32_t nr = right_cnt[b + 1];
+                if (n == 0 || nr == 0) continue;
+                const float cost = kCostNode + kCostTri * (acc.half_area() * n + right_area[b + 1] * nr) / parent_area;
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = a;
+                    best_bin = b;
+                }
+            }
+        }
+
+        if (!force_inner && count <= PRT_LEAF_MAX && !(best_cost < kCostTri * count)) return leaf_ref(s, count);
+
+        uint32_t mid = s;
+        const uint64_t child_cap = (uint64_t)PRT_LEAF_MAX << (levels - 1);
+        if (best_axis >= 0) {
+            const int a = best_axis;
+            const float k = kBins * (1.f - 1e-6f) / (chi[a] - clo[a]);
+            const float c0 = clo[a];
+            auto it = std::partition(prims.begin() + s, prims.begin() + e, [&](const PrimRef& p) {
+                float c = 0.5f * (p.lo[a] + p.hi[a]);
+                int b = std::min(kBins - 1, std::max(0, (int)((c - c0) * k)));
+                return b <= best_bin;
+            });
+            mid = (uint32_t)(it - prims.begin());
+        }
+        if (mid == s || mid == e || std::max<uint64_t>(mid - s, e - mid) > child_cap) {
+            // median split on the longest centroid axis (also the depth-bound fallback)
+            int a = 0;
+            if (chi[1] - clo[1] > chi[a] - clo[a]) a = 1;
+            if (chi[2] - clo[2] > chi[a] - clo[a]) a = 2;
+            mid = s + count / 2;
+            std::nth_element(prims.begin() + s, prims.begin() + mid, prims.begin() + e,
+                             [a](const PrimRef& x, const PrimRef& y) { return x.lo[a] + x.hi[a] < y.lo[a] + y.hi[a]; });
+        }
+
+        const int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        FBox b0, b1;
+        const int32_t r0 = build(s, mid, levels - 1, depth + 1, b0, false);
+        const int32_t r1 = build(mid, e, levels - 1, depth + 1, b1, false);
+        DNode& n = nodes[me];
+        n.c0x[0] = b0.lo[0]; n.c0x[1] = b0.hi[0];
+        n.c0y[0] = b0.lo[1]; n.c0y[1] = b0.hi[1];
+        n.c0z[0] = b0.lo[2]; n.c0z[1] = b0.hi[2];
+        n.c1x[0] = b1.lo[0]; n.c1x[1] = b1.hi[0];
+        n.c1y[0] = b1.lo[1]; n.c1y[1] = b1.hi[1];
+        n.c1z[0] = b1.lo[2]; n.c1z[1] = b1.hi[2];
+        n.ref0 = r0;
+        n.ref1 = r1;
+        n.pad[0] = n.pad[1] = 0;
+        return me;
+    }
+};
+
+} // namespace
+
+bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err) {
+    out.nodes.clear();
+    out.order.clear();
+    out.depth = 0;
+    const size_t n = tris.size();
+    if (n >= ((size_t)1 << 28)) {
+        if (err) *err = "too many triangles for the 28-bit leaf encoding";
+        return false;
+    }
+    if (n == 0) { // trace() short-circuits on n_tris == 0; keep a well-formed root anyway
+        DNode z;
+        std::memset(&z, 0, sizeof(z));
+        z.ref0 = z.ref1 = ~0;
+        out.nodes.push_back(z);
+        return true;
+    }
+    Builder b(out.nodes);
+    b.prims.resize(n);
+    // inflation: covers the rounding of fma(b, 1/d, -o/d) against (b-o)/d for |o| up to ~1e6 scene units
+    double scale = 1.0;
+    for (const HostTri& t : tris)
+        for (int a = 0; a < 3; ++a) scale = std::max(scale, std::max(std::fabs(t.lo[a]), std::fabs(t.hi[a])));
+    const double delta = 1e-9 * scale;
+    for (size_t i = 0; i < n; ++i) {
+        for (int a = 0; a < 3; ++a) {
+            b.prims[i].lo[a] = round_down(tris[i].lo[a] - delta);
+            b.prims[i].hi[a] = round_up(tris[i].hi[a] + delta);
+        }
+        b.prims[i].idx = (uint32_t)i;
+    }
+    FBox root;
+    if (n == 1) {
+        // one triangle: the root tests it through both children (like the reference's span-1 node, BVH.cpp:21-23)
+        b.range_box(0, 1, root);
+        DNode r;
+        std::memset(&r, 0, sizeof(r));
+        r.c0x[0] = r.c1x[0] = root.lo[0]; r.c0x[1] = r.c1x[1] = root.hi[0];
+        r.c0y[0] = r.c1y[0] = root.lo[1]; r.c0y[1] = r.c1y[1] = root.hi[1];
+        r.c0z[0] = r.c1z[0] = root.lo[2]; r.c0z[1] = r.c1z[1] = root.hi[2];
+        r.ref0 = r.ref1 = Builder::leaf_ref(0, 1);
+        out.nodes.push_back(r);
+    } else {
+        out.nodes.reserve(n);
+        b.build(0, (uint32_t)n, kMaxLevels, 0, root, true);
+    }
+    out.depth = b.max_depth;
+    out.order.resize(n);
+    for (size_t i = 0; i < n; ++i) out.order[i] = b.prims[i].idx;
+    return true;
+}
+
+} // namespace prt

@@ -1,0 +1,463 @@
+// prt_api.cpp — the C ABI of libprt_hip.so (include/prt.h).  Host orchestration only: scene
+// preparation on create, SoA upload, kernel launches, counters.  There is no CPU compute path:
+// every compute entry point needs a HIP device and fails with PRT_E_NO_DEVICE / PRT_E_HIP otherwise.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "prt_host.h"
+
+namespace prt {
+int render_blocks_per_cu(bool count);
+void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hits, DCounters* d_ctr, bool count, int n_cu,
+                  hipStream_t st);
+void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
+                   bool count, unsigned grid, hipStream_t st);
+void launch_finalize(const DCamera& C, const DRenderParams& P, const double* d_partial, double* d64, float* d32,
+                     hipStream_t st);
+void launch_sample_lights(const DScene& S, const double* d_origins, size_t n, uint64_t seed, PrtLightSample* d_out,
+                          hipStream_t st);
+void launch_tonemap(const float* d_in, size_t n, uint8_t* d_out, hipStream_t st);
+} // namespace prt
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+} // namespace
+
+#define PRT_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? PRT_E_OOM : PRT_E_HIP,                              \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                             \
+    } while (0)
+
+struct PrtScene {
+    // host side
+    std::vector<prt::HostTri> tris;
+    std::vector<DMaterial> mats;
+    std::vector<DTexture> texs;
+    std::vector<uint8_t> texels;
+    prt::LightTree lights;
+    prt::BuiltBVH bvh;
+    // device side
+    int device = -1;
+    int n_cu = 0;
+    int blocks_per_cu[2] = {0, 0};
+    DScene d{};
+    std::vector<void*> allocs;
+    DCounters* d_ctr = nullptr;
+    double* d_partial = nullptr;
+    size_t partial_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    bool counted = false;
+    PrtCounters last{};
+
+    template <typename T>
+    int up(const std::vector<T>& v, const T** out) {
+        void* p = nullptr;
+        size_t bytes = std::max<size_t>(v.size() * sizeof(T), 256);
+        PRT_HIP(hipMalloc(&p, bytes));
+        allocs.push_back(p);
+        if (!v.empty()) PRT_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+        *out = reinterpret_cast<const T*>(p);
+        return PRT_OK;
+    }
+    void release() {
+        if (device >= 0) (void)hipSetDevice(device);
+        for (void* p : allocs) (void)hipFree(p);
+        allocs.clear();
+        if (d_ctr) (void)hipFree(d_ctr);
+        if (d_partial) (void)hipFree(d_partial);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        d_ctr = nullptr;
+        d_partial = nullptr;
+        ev0 = ev1 = nullptr;
+        partial_cap = 0;
+        device = -1;
+    }
+};
+
+extern "C" {
+
+int prt_abi_version(void) { return PRT_ABI_VERSION; }
+const char* prt_last_error(void) { return g_err.c_str(); }
+
+int prt_device_count(int* n) {
+    if (!n) return fail(PRT_E_INVALID, "prt_device_count: null argument");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        return fail(PRT_E_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *n = c;
+    return PRT_OK;
+}
+
+int prt_scene_create(const PrtSceneDesc* desc, PrtScene** out) {
+    if (!desc || !out) return fail(PRT_E_INVALID, "prt_scene_create: null argument");
+    *out = nullptr;
+    if (desc->n_tris && !desc->vertices) return fail(PRT_E_INVALID, "prt_scene_create: vertices is null");
+    if (desc->n_meshes && (!desc->mesh_first_tri || !desc->mesh_material))
+        return fail(PRT_E_INVALID, "prt_scene_create: mesh arrays are null");
+    if (desc->n_materials && !desc->materials) return fail(PRT_E_INVALID, "prt_scene_create: materials is null");
+    if (desc->n_textures && !desc->textures) return fail(PRT_E_INVALID, "prt_scene_create: textures is null");
+    if (desc->n_meshes) {
+        if (desc->mesh_first_tri[0] != 0 || desc->mesh_first_tri[desc->n_meshes] != desc->n_tris)
+            return fail(PRT_E_INVALID, "prt_scene_create: mesh_first_tri must start at 0 and end at n_tris");
+        for (uint32_t m = 0; m < desc->n_meshes; ++m) {
+            if (desc->mesh_first_tri[m] > desc->mesh_first_tri[m + 1])
+                return fail(PRT_E_INVALID, "prt_scene_create: mesh_first_tri must be ascending");
+            if (desc->mesh_material[m] < 0 || (uint32_t)desc->mesh_material[m] >= desc->n_materials)
+                return fail(PRT_E_INVALID, "prt_scene_create: mesh_material out of range");
+        }
+    } else if (desc->n_tris) {
+        return fail(PRT_E_INVALID, "prt_scene_create: triangles without meshes");
+    }
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+        const PrtMaterial& m = desc->materials[i];
+        if (m.type < PRT_MAT_LAMBERTIAN || m.type > PRT_MAT_EMPTY)
+            return fail(PRT_E_INVALID, "prt_scene_create: unknown material type");
+        if (m.texture >= (int32_t)desc->n_textures) return fail(PRT_E_INVALID, "prt_scene_create: texture index out of range");
+    }
+    PrtScene* s = new (std::nothrow) PrtScene();
+    if (!s) return fail(PRT_E_OOM, "prt_scene_create: out of host memory");
+    try {
+        prt::setup_triangles(*desc, s->tris);
+        prt::setup_materials(*desc, s->mats);
+        s->texs.resize(desc->n_textures);
+        for (uint32_t i = 0; i < desc->n_textures; ++i) {
+            const PrtTexture& t = desc->textures[i];
+            DTexture& o = s->texs[i];
+            o.width = t.width;
+            o.height = t.height;
+            o.channels = t.channels;
+            o.has_data = (t.data && t.width > 0 && t.height > 0 && t.channels > 0) ? 1 : 0;
+            o.offset = s->texels.size();
+            if (o.has_data) s->texels.insert(s->texels.end(), t.data, t.data + (size_t)t.width * t.height * t.channels);
+        }
+        prt::build_light_tree(*desc, s->tris, s->mats, s->lights);
+        std::string err;
+        if (!prt::build_bvh(s->tris, s->bvh, &err)) {
+            delete s;
+            return fail(PRT_E_LIMIT, "prt_scene_create: " + err);
+        }
+    } catch (const std::bad_alloc&) {
+        delete s;
+        return fail(PRT_E_OOM, "prt_scene_create: out of host memory");
+    } catch (const std::exception& e) {
+        delete s;
+        return fail(PRT_E_INVALID, std::string("prt_scene_create: ") + e.what());
+    }
+    s->last.bvh_nodes = s->bvh.nodes.size();
+    s->last.bvh_depth = s->bvh.depth;
+    *out = s;
+    return PRT_OK;
+}
+
+void prt_scene_destroy(PrtScene* s) {
+    if (!s) return;
+    s->release();
+    delete s;
+}
+
+int prt_scene_light_count(const PrtScene* s, uint64_t* n) {
+    if (!s || !n) return fail(PRT_E_INVALID, "prt_scene_light_count: null argument");
+    *n = s->lights.tris.size();
+    return PRT_OK;
+}
+
+int prt_scene_light_order(const PrtScene* s, int32_t* prims, uint64_t cap) {
+    if (!s || (!prims && cap)) return fail(PRT_E_INVALID, "prt_scene_light_order: null argument");
+    if (cap < s->lights.tris.size()) return fail(PRT_E_INVALID, "prt_scene_light_order: buffer too small");
+    for (size_t i = 0; i < s->lights.tris.size(); ++i) prims[i] = s->lights.tris[i].prim;
+    return PRT_OK;
+}
+
+int prt_scene_upload(PrtScene* s, int device) {
+    if (!s) return fail(PRT_E_INVALID, "prt_scene_upload: null scene");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PRT_E_NO_DEVICE, "prt_scene_upload: no HIP device");
+    if (device < 0 || device >= ndev) return fail(PRT_E_INVALID, "prt_scene_upload: device index out of range");
+    s->release();
+    PRT_HIP(hipSetDevice(device));
+    s->device = device;
+    hipDeviceProp_t prop;
+    PRT_HIP(hipGetDeviceProperties(&prop, device));
+    s->n_cu = prop.multiProcessorCount;
+
+    // triangles in BVH leaf order
+    const size_t n = s->tris.size();
+    std::vector<DTri> dt(n);
+    std::vector<DTriShade> ds(n);
+    for (size_t i = 0; i < n; ++i) {
+        const prt::HostTri& T = s->tris[s->bvh.order[i]];
+        DTri& a = dt[i];
+        std::memcpy(a.n, T.normal, 24);
+        a.D = T.D;
+        std::memcpy(a.w, T.w, 24);
+        std::memcpy(a.v0, T.v[0], 24);
+        std::memcpy(a.e0, T.e0, 24);
+        std::memcpy(a.e1, T.e1, 24);
+        DTriShade& b = ds[i];
+        std::memset(&b, 0, sizeof(b));
+        std::memcpy(b.tangent, T.tangent, 24);
+        std::memcpy(b.uv0, T.uv[0], 16);
+        std::memcpy(b.uv1, T.uv[1], 16);
+        std::memcpy(b.uv2, T.uv[2], 16);
+        b.material = T.material;
+        b.prim = T.prim;
+    }
+    std::vector<double> lut(256);
+    for (int i = 0; i < 256; ++i) { // ImageTexture::SRGBToLinear(colorScale * byte), Texture.cpp:52,66-70
+        const double c = (1.0 / 255.0) * i;
+        lut[i] = (c <= 0.04045) ? c * (1. / 12.92) : std::pow((c + 0.055) * (1. / 1.055), 2.4);
+    }
+    DScene& d = s->d;
+    std::memset(&d, 0, sizeof(d));
+    int rc;
+    if ((rc = s->up(s->bvh.nodes, &d.nodes))) return rc;
+    if ((rc = s->up(dt, &d.tris))) return rc;
+    if ((rc = s->up(ds, &d.shade))) return rc;
+    if ((rc = s->up(s->mats, &d.materials))) return rc;
+    if ((rc = s->up(s->texs, &d.textures))) return rc;
+    if ((rc = s->up(s->texels, &d.texels))) return rc;
+    if ((rc = s->up(lut, &d.srgb_lut))) return rc;
+    if ((rc = s->up(s->lights.nodes, &d.light_nodes))) return rc;
+    if ((rc = s->up(s->lights.tris, &d.light_tris))) return rc;
+    d.light_root = s->lights.root;
+    d.n_lights = (int32_t)s->lights.tris.size();
+    d.light_area = s->lights.area;
+    d.n_nodes = (uint32_t)s->bvh.nodes.size();
+    d.n_tris = (uint32_t)n;
+    PRT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_ctr), sizeof(DCounters)));
+    PRT_HIP(hipMemset(s->d_ctr, 0, sizeof(DCounters)));
+    PRT_HIP(hipEventCreate(&s->ev0));
+    PRT_HIP(hipEventCreate(&s->ev1));
+    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false);
+    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true);
+    return PRT_OK;
+}
+
+static int require_uploaded(PrtScene* s, const char* who) {
+    if (!s) return fail(PRT_E_INVALID, std::string(who) + ": null scene");
+    if (s->device < 0) return fail(PRT_E_NO_DEVICE, std::string(who) + ": scene is not uploaded to a HIP device (no CPU path exists)");
+    PRT_HIP(hipSetDevice(s->device));
+    return PRT_OK;
+}
+
+int prt_trace_closest_device(PrtScene* s, const void* d_rays, size_t n, void* d_hits, int count_work, void* stream) {
+    int rc = require_uploaded(s, "prt_trace_closest_device");
+    if (rc) return rc;
+    if (n && (!d_rays || !d_hits)) return fail(PRT_E_INVALID, "prt_trace_closest_device: null buffer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    PRT_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), st));
+    PRT_HIP(hipEventRecord(s->ev0, st));
+    prt::launch_trace(s->d, static_cast<const PrtRay*>(d_rays), n, static_cast<PrtHit*>(d_hits), s->d_ctr, count_work != 0,
+                      s->n_cu, st);
+    PRT_HIP(hipGetLastError());
+    PRT_HIP(hipEventRecord(s->ev1, st));
+    s->timed = true;
+    s->counted = count_work != 0;
+    return PRT_OK;
+}
+
+int prt_trace_closest(PrtScene* s, const PrtRay* rays, size_t n, PrtHit* hits, int count_work) {
+    int rc = require_uploaded(s, "prt_trace_closest");
+    if (rc) return rc;
+    if (n == 0) return PRT_OK;
+    if (!rays || !hits) return fail(PRT_E_INVALID, "prt_trace_closest: null buffer");
+    void *dr = nullptr, *dh = nullptr;
+    PRT_HIP(hipMalloc(&dr, n * sizeof(PrtRay)));
+    hipError_t e = hipMalloc(&dh, n * sizeof(PrtHit));
+    if (e != hipSuccess) {
+        (void)hipFree(dr);
+        return fail(PRT_E_OOM, "prt_trace_closest: hipMalloc failed");
+    }
+    rc = PRT_OK;
+    do {
+        if (hipMemcpy(dr, rays, n * sizeof(PrtRay), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(PRT_E_HIP, "prt_trace_closest: H2D copy failed"); break; }
+        rc = prt_trace_closest_device(s, dr, n, dh, count_work, nullptr);
+        if (rc) break;
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) { rc = fail(PRT_E_HIP, std::string("prt_trace_closest: ") + hipGetErrorString(e)); break; }
+        if (hipMemcpy(hits, dh, n * sizeof(PrtHit), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(PRT_E_HIP, "prt_trace_closest: D2H copy failed"); break; }
+    } while (0);
+    (void)hipFree(dr);
+    (void)hipFree(dh);
+    return rc;
+}
+
+int prt_sample_lights(PrtScene* s, const double* origins, size_t n, uint64_t seed, PrtLightSample* out) {
+    int rc = require_uploaded(s, "prt_sample_lights");
+    if (rc) return rc;
+    if (n == 0) return PRT_OK;
+    if (!origins || !out) return fail(PRT_E_INVALID, "prt_sample_lights: null buffer");
+    if (s->d.n_lights == 0) return fail(PRT_E_INVALID, "prt_sample_lights: scene has no emissive mesh");
+    void *dorg = nullptr, *dout = nullptr;
+    PRT_HIP(hipMalloc(&dorg, n * 3 * sizeof(double)));
+    if (hipMalloc(&dout, n * sizeof(PrtLightSample)) != hipSuccess) {
+        (void)hipFree(dorg);
+        return fail(PRT_E_OOM, "prt_sample_lights: hipMalloc failed");
+    }
+    rc = PRT_OK;
+    do {
+        if (hipMemcpy(dorg, origins, n * 3 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(PRT_E_HIP, "prt_sample_lights: H2D copy failed"); break; }
+        prt::launch_sample_lights(s->d, static_cast<const double*>(dorg), n, seed, static_cast<PrtLightSample*>(dout), nullptr);
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) { rc = fail(PRT_E_HIP, std::string("prt_sample_lights: ") + hipGetErrorString(e)); break; }
+        if (hipMemcpy(out, dout, n * sizeof(PrtLightSample), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(PRT_E_HIP, "prt_sample_lights: D2H copy failed"); break; }
+    } while (0);
+    (void)hipFree(dorg);
+    (void)hipFree(dout);
+    return rc;
+}
+
+int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* p, void* d_rgb_f64, void* d_rgb_f32,
+                      int count_work, void* stream) {
+    int rc = require_uploaded(s, "prt_render_device");
+    if (rc) return rc;
+    if (!cam || !p) return fail(PRT_E_INVALID, "prt_render_device: null argument");
+    if (cam->width < 1 || cam->height < 1) return fail(PRT_E_INVALID, "prt_render_device: bad image size");
+    if (p->spp < 1) return fail(PRT_E_INVALID, "prt_render_device: spp must be >= 1");
+    if (p->precision != PRT_PRECISION_F64) return fail(PRT_E_INVALID, "prt_render_device: unsupported precision");
+    if (p->nranks < 1 || p->rank < 0 || p->rank >= p->nranks) return fail(PRT_E_INVALID, "prt_render_device: bad rank/nranks");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+
+    DCamera C;
+    prt::setup_camera(*cam, C);
+    DRenderParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.spp = p->spp;
+    P.max_depth = p->max_depth;
+    P.sample_lights = p->sample_lights ? 1 : 0;
+    P.rr = p->russian_roulette;
+    for (int c = 0; c < 3; ++c) P.background[c] = p->background[c];
+    P.seed = p->seed;
+    int tile = p->tile_size > 0 ? p->tile_size : 32;
+    tile = std::max(8, (tile + 7) / 8 * 8);
+    P.tile = tile;
+    P.tiles_x = (C.width + tile - 1) / tile;
+    P.tiles_y = (C.height + tile - 1) / tile;
+    P.n_tiles = P.tiles_x * P.tiles_y;
+    P.rank = p->rank;
+    P.nranks = p->nranks;
+    P.owned_tiles = P.n_tiles > P.rank ? (P.n_tiles - P.rank + P.nranks - 1) / P.nranks : 0;
+    P.items_per_chunk = (uint64_t)P.owned_tiles * tile * tile;
+    const bool count = count_work != 0;
+    const int bpc = s->blocks_per_cu[count ? 1 : 0];
+    const uint64_t lanes = (uint64_t)s->n_cu * bpc * PRT_BLOCK;
+    int chunks = p->sample_chunks;
+    if (chunks <= 0) { // enough items that the dynamic queue levels the tail: >= 8 items per resident lane
+        chunks = 1;
+        if (P.items_per_chunk) chunks = (int)std::min<uint64_t>(64, (8 * lanes + P.items_per_chunk - 1) / P.items_per_chunk);
+    }
+    chunks = std::max(1, std::min(chunks, p->spp));
+    P.chunks = chunks;
+    P.n_items = P.items_per_chunk * (uint64_t)chunks;
+
+    const size_t need = std::max<size_t>(P.n_items * 3, 3);
+    if (need > s->partial_cap) {
+        if (s->d_partial) (void)hipFree(s->d_partial);
+        s->d_partial = nullptr;
+        s->partial_cap = 0;
+        PRT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_partial), need * sizeof(double)));
+        s->partial_cap = need;
+    }
+    const size_t npx = (size_t)C.width * C.height * 3;
+    PRT_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), st));
+    if (d_rgb_f64) PRT_HIP(hipMemsetAsync(d_rgb_f64, 0, npx * sizeof(double), st));
+    if (d_rgb_f32) PRT_HIP(hipMemsetAsync(d_rgb_f32, 0, npx * sizeof(float), st));
+    PRT_HIP(hipEventRecord(s->ev0, st));
+    if (P.n_items) {
+        const uint64_t want = (P.n_items + PRT_BLOCK - 1) / PRT_BLOCK;
+        const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)s->n_cu * bpc));
+        prt::launch_render(s->d, C, P, s->d_partial, s->d_ctr, count, grid, st);
+        PRT_HIP(hipGetLastError());
+    }
+    PRT_HIP(hipEventRecord(s->ev1, st));
+    if (P.n_items) {
+        prt::launch_finalize(C, P, s->d_partial, static_cast<double*>(d_rgb_f64), static_cast<float*>(d_rgb_f32), st);
+        PRT_HIP(hipGetLastError());
+    }
+    s->timed = true;
+    s->counted = count;
+    return PRT_OK;
+}
+
+int prt_render(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* p, double* rgb_f64, float* rgb_f32) {
+    int rc = require_uploaded(s, "prt_render");
+    if (rc) return rc;
+    if (!cam || !p) return fail(PRT_E_INVALID, "prt_render: null argument");
+    if (cam->width < 1 || cam->height < 1) return fail(PRT_E_INVALID, "prt_render: bad image size");
+    const size_t npx = (size_t)cam->width * cam->height * 3;
+    void *d64 = nullptr, *d32 = nullptr;
+    if (rgb_f64) PRT_HIP(hipMalloc(&d64, npx * sizeof(double)));
+    if (rgb_f32) {
+        if (hipMalloc(&d32, npx * sizeof(float)) != hipSuccess) {
+            if (d64) (void)hipFree(d64);
+            return fail(PRT_E_OOM, "prt_render: hipMalloc failed");
+        }
+    }
+    rc = prt_render_device(s, cam, p, d64, d32, 0, nullptr);
+    if (rc == PRT_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) rc = fail(PRT_E_HIP, std::string("prt_render: ") + hipGetErrorString(e));
+    }
+    if (rc == PRT_OK && rgb_f64 && hipMemcpy(rgb_f64, d64, npx * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(PRT_E_HIP, "prt_render: D2H copy failed");
+    if (rc == PRT_OK && rgb_f32 && hipMemcpy(rgb_f32, d32, npx * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(PRT_E_HIP, "prt_render: D2H copy failed");
+    if (d64) (void)hipFree(d64);
+    if (d32) (void)hipFree(d32);
+    return rc;
+}
+
+int prt_get_counters(PrtScene* s, PrtCounters* out) {
+    if (!s || !out) return fail(PRT_E_INVALID, "prt_get_counters: null argument");
+    PrtCounters c = s->last;
+    c.bvh_nodes = s->bvh.nodes.size();
+    c.bvh_depth = s->bvh.depth;
+    if (s->device >= 0 && s->timed) {
+        PRT_HIP(hipSetDevice(s->device));
+        PRT_HIP(hipEventSynchronize(s->ev1));
+        float ms = 0.f;
+        PRT_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        DCounters h;
+        PRT_HIP(hipMemcpy(&h, s->d_ctr, sizeof(h), hipMemcpyDeviceToHost));
+        c.rays_closest = h.rays_closest;
+        c.rays_shadow = h.rays_shadow;
+        c.node_fetches = h.node_fetches;
+        c.tri_tests = h.tri_tests;
+        c.samples = h.samples;
+        c.kernel_ms = ms;
+    }
+    s->last = c;
+    *out = c;
+    return PRT_OK;
+}
+
+int prt_tonemap_srgb8(PrtScene* s, const void* d_rgb_f32, int width, int height, void* d_rgb_u8, void* stream) {
+    int rc = require_uploaded(s, "prt_tonemap_srgb8");
+    if (rc) return rc;
+    if (!d_rgb_f32 || !d_rgb_u8 || width < 1 || height < 1) return fail(PRT_E_INVALID, "prt_tonemap_srgb8: bad argument");
+    prt::launch_tonemap(static_cast<const float*>(d_rgb_f32), (size_t)width * height * 3, static_cast<uint8_t*>(d_rgb_u8),
+                        reinterpret_cast<hipStream_t>(stream));
+    PRT_HIP(hipGetLastError());
+    return PRT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,514 @@
+// prt_device.h — device functions of the gfx950 path tracer (wave64, fp64 arithmetic).
+//
+// Everything here is written for CDNA4 directly: per-lane BVH2 traversal with a lane-strided LDS
+// stack (conflict-free: entry e of lane l lives at word e*64+l), 64-byte fp32-outward-rounded node
+// records (two per 128-byte L2 line), 128-byte fp64 triangle records, fp64 shading.
+//
+// Reference behaviour followed by each function is cited as file:line of Zoz4/Pooraytracer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "prt_types.h"
+
+#define PRT_DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------ dvec3 subset (glm semantics)
+struct d3 {
+    double x, y, z;
+};
+struct d2 {
+    double x, y;
+};
+PRT_DEV d3 mk3(double x, double y, double z) { return d3{x, y, z}; }
+PRT_DEV d3 ld3(const double* p) { return d3{p[0], p[1], p[2]}; }
+PRT_DEV d3 operator+(d3 a, d3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+PRT_DEV d3 operator-(d3 a, d3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+PRT_DEV d3 operator-(d3 a) { return {-a.x, -a.y, -a.z}; }
+PRT_DEV d3 operator*(d3 a, d3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+PRT_DEV d3 operator*(d3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+PRT_DEV d3 operator*(double s, d3 a) { return {s * a.x, s * a.y, s * a.z}; }
+PRT_DEV d3 operator/(d3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+PRT_DEV double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PRT_DEV d3 cross(d3 x, d3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
+PRT_DEV double length(d3 v) { return sqrt(dot(v, v)); }
+PRT_DEV d3 normalize(d3 v) { return v * (1.0 / sqrt(dot(v, v))); }
+
+#define PRT_PI 3.14159265358979323846
+#define PRT_INV_PI 0.31830988618379067154
+#define PRT_INV_2PI 0.15915494309189533577
+#define PRT_PI_OVER_2 1.57079632679489661923
+#define PRT_PI_OVER_4 0.78539816339744830961
+#define PRT_INF __builtin_huge_val()
+
+// ------------------------------------------------------------------ keyed counter RNG
+// Replaces the reference's global std::rand() (RandomNumberGenerator.h:16-19) by a stream keyed on
+// (seed, pixel, sample); each draw yields 31 bits so xi = r / 2^31 has rand()'s granularity.
+PRT_DEV uint64_t mix64(uint64_t z) {
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return z;
+}
+struct Rng {
+    uint64_t s;
+    PRT_DEV void seed(uint64_t seed, uint64_t pixel, uint64_t sample) {
+        s = mix64(seed + 0x9E3779B97F4A7C15ULL * (pixel + 1));
+        s = mix64(s ^ (0xD1B54A32D192ED03ULL * (sample + 1)));
+    }
+    PRT_DEV double next() {
+        s += 0x9E3779B97F4A7C15ULL;
+        uint32_t r = (uint32_t)(mix64(s) >> 33);
+        return (double)r * (1.0 / 2147483648.0);
+    }
+};
+
+// ------------------------------------------------------------------ BVH traversal
+struct HitInfo {
+    double t;      // closest accepted t (== tmax on miss)
+    double alpha, beta;
+    int32_t tri;   // BVH-order triangle index, -1 on miss
+};
+
+struct WorkCount {
+    uint32_t nodes, tris;
+};
+
+// Triangle::Hit + IsInterior (Triangle.cpp:54-83,100-113): same expressions, inclusive interval.
+PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, double tmin, double tmax, double& t_out, double& a_out,
+                      double& b_out) {
+    const double4* q = reinterpret_cast<const double4*>(T);
+    double4 q0 = q[0], q1 = q[1];
+    d3 n = mk3(q0.x, q0.y, q0.z);
+    double denom = dot(n, d);
+    if (fabs(denom) < 1e-8) return false;
+    double t = (q0.w - dot(n, o)) / denom;
+    if (!(tmin <= t && t <= tmax)) return false;
+    // record = n[3] D | w[3] v0.x | v0.yz e0.xy | e0.z e1[3]
+    double4 q2 = q[2], q3 = q[3];
+    d3 w = mk3(q1.x, q1.y, q1.z);
+    d3 v0 = mk3(q1.w, q2.x, q2.y);
+    d3 e0 = mk3(q2.z, q2.w, q3.x);
+    d3 e1 = mk3(q3.y, q3.z, q3.w);
+    d3 p = o + d * t;
+    d3 v0p = p - v0;
+    double alpha = dot(w, cross(v0p, e1));
+    double beta = dot(w, cross(e0, v0p));
+    if (alpha != alpha || beta != beta) return false;
+    if ((alpha < 0) || (beta < 0) || (alpha + beta > 1)) return false;
+    t_out = t;
+    a_out = alpha;
+    b_out = beta;
+    return true;
+}
+
+// Closest hit in [tmin, tmax] (replaces world.Hit: HittableList.h:26-39 -> BVH.cpp:51-61 -> AABB.cpp:38-64).
+// The result is tree-independent (closest accepted triangle; on exactly equal t the later-tested one
+// wins, as in the reference).  `early_t`: traversal stops as soon as a hit with t < early_t is
+// accepted (shadow rays: anything that close is an occluder for certain); pass -inf for closest-hit.
+// `stk` points at this lane's column of the wave's LDS stack (stride 64 words).
+template <bool COUNT>
+PRT_DEV void trace(const DScene& S, d3 o, d3 d, double tmin, double tmax, double early_t, HitInfo& hit,
+                   uint32_t* stk, WorkCount& wc) {
+    const double idx = 1.0 / d.x, idy = 1.0 / d.y, idz = 1.0 / d.z;
+    const double oix = -o.x * idx, oiy = -o.y * idy, oiz = -o.z * idz;
+    hit.t = tmax;
+    hit.tri = -1;
+    hit.alpha = 0.0;
+    hit.beta = 0.0;
+    int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+            float4 a = np[0], b = np[1], c = np[2];
+            int2 refs = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(S.nodes + cur) + 48);
+            if (COUNT) wc.nodes++;
+            // child 0: a = (lo.x,hi.x,lo.y,hi.y), b.xy = (lo.z,hi.z)
+            double t0 = fma((double)a.x, idx, oix), t1 = fma((double)a.y, idx, oix);
+            double tn0 = fmin(t0, t1), tf0 = fmax(t0, t1);
+            t0 = fma((double)a.z, idy, oiy);
+            t1 = fma((double)a.w, idy, oiy);
+            tn0 = fmax(tn0, fmin(t0, t1));
+            tf0 = fmin(tf0, fmax(t0, t1));
+            t0 = fma((double)b.x, idz, oiz);
+            t1 = fma((double)b.y, idz, oiz);
+            tn0 = fmax(fmax(tn0, fmin(t0, t1)), tmin);
+            tf0 = fmin(fmin(tf0, fmax(t0, t1)), hit.t);
+            // child 1: b.zw = (lo.x,hi.x), c = (lo.y,hi.y,lo.z,hi.z)
+            t0 = fma((double)b.z, idx, oix);
+            t1 = fma((double)b.w, idx, oix);
+            double tn1 = fmin(t0, t1), tf1 = fmax(t0, t1);
+            t0 = fma((double)c.x, idy, oiy);
+            t1 = fma((double)c.y, idy, oiy);
+            tn1 = fmax(tn1, fmin(t0, t1));
+            tf1 = fmin(tf1, fmax(t0, t1));
+            t0 = fma((double)c.z, idz, oiz);
+            t1 = fma((double)c.w, idz, oiz);
+            tn1 = fmax(fmax(tn1, fmin(t0, t1)), tmin);
+            tf1 = fmin(fmin(tf1, fmax(t0, t1)), hit.t);
+            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+            if (h0 && h1) {
+                const bool swap = tn1 < tn0;
+                const int32_t nearRef = swap ? refs.y : refs.x;
+                const int32_t farRef = swap ? refs.x : refs.y;
+                stk[sp * 64] = (uint32_t)farRef;
+                sp++;
+                cur = nearRef;
+            } else if (h0) {
+                cur = refs.x;
+            } else if (h1) {
+                cur = refs.y;
+            } else {
+                if (sp == 0) break;
+                sp--;
+                cur = (int32_t)stk[sp * 64];
+            }
+        } else {
+            const uint32_t enc = ~(uint32_t)cur;
+            const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
+            bool stop = false;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                double t, al, be;
+                if (COUNT) wc.tris++;
+                if (tri_test(S.tris + first + i, o, d, tmin, hit.t, t, al, be)) {
+                    hit.t = t;
+                    hit.alpha = al;
+                    hit.beta = be;
+                    hit.tri = (int32_t)(first + i);
+                    if (t < early_t) stop = true;
+                }
+            }
+            if (stop || sp == 0) break;
+            sp--;
+            cur = (int32_t)stk[sp * 64];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ textures (Texture.cpp:22-71)
+PRT_DEV d3 tex_pixel(const DScene& S, const DTexture& tx, int x, int y) {
+    const uint8_t* p = S.texels + tx.offset + (size_t)(y * tx.width + x) * tx.channels;
+    if (tx.channels >= 3) return mk3(S.srgb_lut[p[0]], S.srgb_lut[p[1]], S.srgb_lut[p[2]]);
+    const double g = (1.0 / 255.0) * p[0];
+    return mk3(g, g, g);
+}
+PRT_DEV d3 tex_value(const DScene& S, int ti, double u, double v) {
+    const DTexture tx = S.textures[ti];
+    if (!tx.has_data) return mk3(0., 1., 1.);
+    u = fmin(fmax(u, 0.0), 1.0); // std::clamp
+    v = fmin(fmax(v, 0.0), 1.0);
+    double x = u * (tx.width - 1.);
+    double y = (1. - v) * (tx.height - 1.);
+    int x0 = (int)x, y0 = (int)y;
+    int x1 = min(x0 + 1, tx.width - 1), y1 = min(y0 + 1, tx.height - 1);
+    double fx = x - x0, fy = y - y0;
+    d3 c00 = tex_pixel(S, tx, x0, y0), c10 = tex_pixel(S, tx, x1, y0);
+    d3 c01 = tex_pixel(S, tx, x0, y1), c11 = tex_pixel(S, tx, x1, y1);
+    d3 c0 = c00 * (1 - fx) + c10 * fx;
+    d3 c1 = c01 * (1 - fx) + c11 * fx;
+    return c0 * (1 - fy) + c1 * fy;
+}
+
+// ------------------------------------------------------------------ samplers (RandomNumberGenerator.h:39-73)
+PRT_DEV d2 disk_concentric(d2 u) {
+    d2 off = {2. * u.x - 1., 2. * u.y - 1.};
+    if (off.x == 0. && off.y == 0.) return {0., 0.};
+    double theta, r;
+    if (fabs(off.x) > fabs(off.y)) {
+        r = off.x;
+        theta = PRT_PI_OVER_4 * (off.y / off.x);
+    } else {
+        r = off.y;
+        theta = PRT_PI_OVER_2 - PRT_PI_OVER_4 * (off.x / off.y);
+    }
+    double sn, cs;
+    sincos(theta, &sn, &cs);
+    return {r * cs, r * sn};
+}
+// SampleCosineHemisphere: glm::dvec2(RandomDouble(), RandomDouble()) as compiled by g++ (right-to-left):
+// u.y = first draw, u.x = second draw.
+PRT_DEV d3 cosine_hemisphere(Rng& rng) {
+    double first = rng.next();
+    double second = rng.next();
+    d2 dd = disk_concentric(d2{second, first});
+    double z = sqrt(fmax(0.0, 1. - dd.x * dd.x - dd.y * dd.y));
+    return mk3(dd.x, dd.y, z);
+}
+
+// ------------------------------------------------------------------ shading frame (Material.h:76-98)
+struct Frame {
+    d3 n, t; // record.normal (face-forwarded), record.tangent
+};
+PRT_DEV d3 world_to_local(d3 w, const Frame& f) {
+    d3 bit = cross(f.t, f.n);
+    return mk3(dot(w, f.t), dot(w, bit), dot(w, f.n));
+}
+PRT_DEV d3 local_to_world(d3 l, const Frame& f) {
+    d3 bit = cross(f.t, f.n);
+    return normalize(l.x * f.t + l.y * bit + l.z * f.n);
+}
+PRT_DEV d3 reflect_z(d3 wo) { // Reflect(wo, (0,0,1)) = -wo + 2*dot(wo,n)*n
+    double dn = wo.x * 0. + wo.y * 0. + wo.z * 1.;
+    d3 n2 = (2. * dn) * mk3(0., 0., 1.);
+    return -wo + n2;
+}
+PRT_DEV d3 reflect(d3 wo, d3 n) { return -wo + 2. * dot(wo, n) * n; }
+
+// ------------------------------------------------------------------ CookTorrance (Material.h:368-521, MaterialUtils.h)
+struct Cx {
+    double re, im;
+};
+PRT_DEV Cx cx(double r, double i = 0.0) { return {r, i}; }
+PRT_DEV Cx operator+(Cx a, Cx b) { return {a.re + b.re, a.im + b.im}; }
+PRT_DEV Cx operator-(Cx a, Cx b) { return {a.re - b.re, a.im - b.im}; }
+PRT_DEV Cx operator*(Cx a, Cx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+PRT_DEV Cx operator/(Cx a, Cx z) {
+    double scale = 1 / (z.re * z.re + z.im * z.im);
+    return {scale * (a.re * z.re + a.im * z.im), scale * (a.im * z.re - a.re * z.im)};
+}
+PRT_DEV double cnorm(Cx z) { return z.re * z.re + z.im * z.im; }
+PRT_DEV Cx csqrt_(Cx z) { // MaterialUtils.h:54-65
+    double n = sqrt(cnorm(z)), t1 = sqrt(.5 * (n + fabs(z.re))), t2 = .5 * z.im / t1;
+    if (n == 0) return cx(0);
+    if (z.re >= 0) return {t1, t2};
+    return {fabs(t2), copysign(t1, z.im)};
+}
+PRT_DEV double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
+PRT_DEV double sqr(double v) { return v * v; }
+PRT_DEV double fr_complex(double cosTheta_i, Cx eta) { // MaterialUtils.h:100-111
+    cosTheta_i = clampd(cosTheta_i, 0, 1);
+    double sin2Theta_i = 1 - sqr(cosTheta_i);
+    Cx sin2Theta_t = cx(sin2Theta_i) / (eta * eta);
+    Cx cosTheta_t = csqrt_(cx(1) - sin2Theta_t);
+    Cx r_parl = (eta * cx(cosTheta_i) - cosTheta_t) / (eta * cx(cosTheta_i) + cosTheta_t);
+    Cx r_perp = (cx(cosTheta_i) - eta * cosTheta_t) / (cx(cosTheta_i) + eta * cosTheta_t);
+    return (cnorm(r_parl) + cnorm(r_perp)) / 2;
+}
+PRT_DEV double cos2theta(d3 w) { return sqr(w.z); }
+PRT_DEV double sin2theta(d3 w) { return fmax(0., 1 - cos2theta(w)); }
+PRT_DEV double tan2theta(d3 w) { return sin2theta(w) / cos2theta(w); }
+PRT_DEV double cosphi(d3 w) {
+    double st = sqrt(sin2theta(w));
+    return (st == 0) ? 1 : clampd(w.x / st, -1, 1);
+}
+PRT_DEV double sinphi(d3 w) {
+    double st = sqrt(sin2theta(w));
+    return (st == 0) ? 0 : clampd(w.y / st, -1, 1);
+}
+PRT_DEV double ct_D(const DMaterial& m, d3 wm) {
+    double t2 = tan2theta(wm);
+    if (isinf(t2)) return 0;
+    double cos4 = sqr(cos2theta(wm));
+    double e = t2 * (sqr(cosphi(wm) / m.alpha_x) + sqr(sinphi(wm) / m.alpha_y));
+    return 1 / (PRT_PI * m.alpha_x * m.alpha_y * cos4 * sqr(1 + e));
+}
+PRT_DEV double ct_lambda(const DMaterial& m, d3 w) {
+    double t2 = tan2theta(w);
+    if (isinf(t2)) return 0;
+    double alpha2 = sqr(cosphi(w) * m.alpha_x) + sqr(sinphi(w) * m.alpha_y);
+    return (sqrt(1 + alpha2 * t2) - 1) / 2;
+}
+PRT_DEV double ct_G1(const DMaterial& m, d3 w) { return 1 / (1 + ct_lambda(m, w)); }
+PRT_DEV double ct_G(const DMaterial& m, d3 wo, d3 wi) { return 1 / (1 + ct_lambda(m, wo) + ct_lambda(m, wi)); }
+PRT_DEV double ct_Dv(const DMaterial& m, d3 w, d3 wm) {
+    return ct_G1(m, w) / fabs(w.z) * ct_D(m, wm) * fabs(dot(w, wm));
+}
+PRT_DEV d3 ct_fresnel(const DMaterial& m, d3 wo, d3 wm) {
+    double c = fabs(dot(wo, wm));
+    return mk3(fr_complex(c, cx(m.eta[0], m.k[0])), fr_complex(c, cx(m.eta[1], m.k[1])),
+               fr_complex(c, cx(m.eta[2], m.k[2])));
+}
+PRT_DEV d3 ct_sample_wm(const DMaterial& m, d3 w, d2 u) { // Material.h:412-435
+    d3 wh = normalize(mk3(m.alpha_x * w.x, m.alpha_y * w.y, w.z));
+    if (wh.z < 0) wh = -wh;
+    d3 T1 = (wh.z < 0.99999) ? normalize(cross(mk3(0., 0., 1.), wh)) : mk3(1, 0, 0);
+    d3 T2 = cross(wh, T1);
+    double r = sqrt(u.x), theta = 2 * PRT_PI * u.y; // SampleUniformDiskPolar
+    double sn, cs;
+    sincos(theta, &sn, &cs);
+    d2 p = {r * cs, r * sn};
+    double h = sqrt(1 - sqr(p.x));
+    double lx = (1 + wh.z) / 2;
+    p.y = (1 - lx) * h + lx * p.y; // Lerp
+    double pz = sqrt(fmax(0., 1. - (sqr(p.x) + sqr(p.y))));
+    d3 nh = p.x * T1 + p.y * T2 + pz * wh;
+    return normalize(mk3(m.alpha_x * nh.x, m.alpha_y * nh.y, fmax(1e-6, nh.z)));
+}
+
+// ------------------------------------------------------------------ Material::Eval for NEE
+// Lambertian Material.h:128-130; Phong :227-248 (draws one uniform); CookTorrance :474-496.
+PRT_DEV d3 mat_kd(const DScene& S, const DMaterial& m, d2 uv) {
+    return m.texture >= 0 ? tex_value(S, m.texture, uv.x, uv.y) : ld3(m.kd);
+}
+PRT_DEV d3 mat_ks(const DScene& S, const DMaterial& m, d2 uv) { // Phong(mapKd,...) stores the map in Ks too (:178-181)
+    return m.texture >= 0 ? tex_value(S, m.texture, uv.x, uv.y) : ld3(m.ks);
+}
+PRT_DEV d3 mat_eval(const DScene& S, const DMaterial& m, d3 wi, d3 wo, d2 uv, Rng& rng) {
+    switch (m.type) {
+    case 0: return mat_kd(S, m, uv) * PRT_INV_PI;
+    case 1: {
+        double u = rng.next();
+        if (u < m.pkd) {
+            if (wi.z <= 0) return mk3(0, 0, 0);
+            return mat_kd(S, m, uv) * PRT_INV_PI;
+        } else if (m.pkd <= u && u < m.pkd + m.pks) {
+            if (wi.z <= 0) return mk3(0, 0, 0);
+            d3 lr = normalize(reflect_z(wo));
+            double ca = fmax(0., dot(wi, lr));
+            if (ca <= 0.) return mk3(0, 0, 0);
+            return mat_ks(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pow(ca, m.ns);
+        }
+        return mk3(0, 0, 0);
+    }
+    case 3: {
+        if (!(wo.z * wi.z > 0)) return mk3(0, 0, 0);
+        double co = fabs(wo.z), ci = fabs(wi.z);
+        if (ci == 0 || co == 0) return mk3(0, 0, 0);
+        d3 wm = wi + wo;
+        if (sqr(wm.x) + sqr(wm.y) + sqr(wm.z) == 0) return mk3(0, 0, 0);
+        wm = normalize(wm);
+        d3 F = ct_fresnel(m, wo, wm);
+        return ct_D(m, wm) * F * ct_G(m, wo, wi) / (4 * ci * co);
+    }
+    default: return mk3(0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------ Material::Scatter
+// Returns false when the reference's Scatter returns false.  `wi_world` is the (normalised) scattered
+// direction, `att` = f * cos / pdf.  rd = incoming ray direction (unnormalised for camera rays).
+PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame& f, d2 uv, Rng& rng, d3& att,
+                         d3& wi_world) {
+    switch (m.type) {
+    case 0: { // Lambertian, Material.h:106-151
+        d3 wi = cosine_hemisphere(rng);
+        while (wi.z <= 0.) wi = cosine_hemisphere(rng);
+        double pdf = wi.z * PRT_INV_PI;
+        d3 fr = mat_kd(S, m, uv) * PRT_INV_PI;
+        wi_world = local_to_world(wi, f);
+        att = fr * wi.z / pdf;
+        return true;
+    }
+    case 1: { // PhoneReflectance, Material.h:183-285
+        d3 wo = world_to_local(-rd, f);
+        d3 wi = mk3(0, 0, 0), fr = mk3(0, 0, 0);
+        double pdf = 0;
+        double u = rng.next();
+        if (u < m.pkd) {
+            wi = cosine_hemisphere(rng);
+            while (wi.z <= 0.) wi = cosine_hemisphere(rng);
+            pdf = wi.z * PRT_INV_PI;
+            fr = mat_kd(S, m, uv) * PRT_INV_PI;
+        } else if (m.pkd <= u && u < m.pkd + m.pks) {
+            double u1 = rng.next(), u2 = rng.next();
+            double alpha = acos(pow(u1, 1.0 / (m.ns + 1.0)));
+            double phi = 2.0 * PRT_PI * u2;
+            double sa, ca, sp, cp;
+            sincos(alpha, &sa, &ca);
+            sincos(phi, &sp, &cp);
+            d3 rw = mk3(sa * cp, sa * sp, ca);
+            // ReflectiveSpaceToLocal, Material.h:299-311
+            d3 lr = normalize(reflect_z(wo));
+            d3 V = (fabs(lr.x) > 0.9 ? mk3(0., 1., 0.) : mk3(1., 0., 0.));
+            d3 T = normalize(cross(V, lr));
+            d3 B = cross(lr, T);
+            wi = rw.x * T + rw.y * B + rw.z * lr;
+            // SpecularPDF, Material.h:255-261
+            if (wi.z <= 0.) pdf = 0.0;
+            else pdf = (m.ns + 1.0) * PRT_INV_2PI * pow(dot(wi, lr), m.ns);
+            double lca = fmax(0.0, dot(wi, lr));
+            if (wi.z > 0. && lca > 0.) fr = mat_ks(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pow(lca, m.ns);
+        }
+        wi_world = local_to_world(wi, f);
+        if (pdf > 0. && wi.z > 0) att = fr * wi.z / pdf;
+        else att = mk3(0, 0, 0); // reference leaves it unassigned (Material.h:280-282); defined 0 (B13)
+        return true;
+    }
+    case 2: { // PerfectMirror, Material.h:334-363
+        d3 wo = world_to_local(-rd, f);
+        d3 wi = reflect_z(wo);
+        double c = wi.z;
+        d3 fr = mk3(1.0 / c, 1.0 / c, 1.0 / c);
+        wi_world = local_to_world(wi, f);
+        att = fr * c / 1.0;
+        return true;
+    }
+    case 3: { // CookTorrance, Material.h:437-516
+        d3 wo = normalize(world_to_local(-rd, f));
+        if (wo.z == 0) return false;
+        double first = rng.next();
+        double second = rng.next();
+        d3 wm = ct_sample_wm(m, wo, d2{second, first});
+        d3 wi = reflect(wo, wm);
+        if (!(wo.z * wi.z > 0)) return false;
+        double pdf = ct_Dv(m, wo, wm) / (4. * fabs(dot(wo, wm)));
+        double co = fabs(wo.z), ci = fabs(wi.z);
+        if (ci == 0 || co == 0) return false;
+        d3 F = ct_fresnel(m, wo, wm);
+        d3 fr = ct_D(m, wm) * F * ct_G(m, wo, wi) / (4. * ci * co);
+        att = fr * wi.z / pdf;
+        wi_world = local_to_world(wi, f);
+        return true;
+    }
+    default: return false; // DiffuseLight / Debug / Empty: Material::Scatter base (Material.h:57-59)
+    }
+}
+
+// ------------------------------------------------------------------ lights.Sample
+// HittableList::Sample (HittableList.h:44-59, one discarded draw) -> BVHNode::Sample (BVH.cpp:62-67,
+// p = sqrt(xi)*A truncated to float) -> TraverseSample (BVH.cpp:86-100) -> Triangle::Sample
+// (Triangle.cpp:84-93).  pdf = (1/area)*area/totalArea evaluated in that order.
+struct LightPick {
+    d3 pos, n;
+    double pdf;
+    int32_t tri; // index into light_tris
+    bool front;
+};
+PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng) {
+    (void)rng.next();
+    double p = sqrt(rng.next()) * S.light_area;
+    float pf = (float)p;
+    int32_t node = S.light_root;
+    while (node >= 0) {
+        const DLightNode ln = S.light_nodes[node];
+        if ((double)pf < ln.left_area) node = ln.left;
+        else {
+            pf = (float)((double)pf - ln.left_area);
+            node = ln.right;
+        }
+    }
+    LightPick lp;
+    lp.tri = ~node;
+    const DLightTri* lt = S.light_tris + lp.tri;
+    double x = sqrt(rng.next());
+    double y = rng.next();
+    d3 v0 = ld3(lt->v0), v1 = ld3(lt->v1), v2 = ld3(lt->v2), n = ld3(lt->n);
+    lp.pos = v0 * (1.0 - x) + v1 * (x * (1.0 - y)) + v2 * (x * y);
+    d3 dir = lp.pos - origin;
+    lp.front = dot(dir, n) < 0.;
+    lp.n = lp.front ? n : -n;
+    double pdf = 1.0 / lt->area;
+    pdf *= lt->area;
+    pdf /= S.light_area;
+    lp.pdf = pdf;
+    return lp;
+}
+
+// ------------------------------------------------------------------ tile <-> pixel mapping (multi-GPU sharding)
+// Owned-pixel index -> pixel.  Tiles are dealt round-robin over ranks; inside a tile pixels are
+// visited in 8x8 blocks so the 64 lanes of a wave start on one compact block.
+PRT_DEV bool owned_to_pixel(const DRenderParams& P, const DCamera& C, uint64_t oi, int& px, int& py) {
+    const uint32_t tt = (uint32_t)(P.tile * P.tile);
+    uint32_t ot = (uint32_t)(oi / tt), w = (uint32_t)(oi % tt);
+    uint32_t k = (uint32_t)P.rank + ot * (uint32_t)P.nranks;
+    if (k >= (uint32_t)P.n_tiles) return false;
+    uint32_t tx = k % (uint32_t)P.tiles_x, ty = k / (uint32_t)P.tiles_x;
+    uint32_t bpr = (uint32_t)P.tile / 8u;
+    uint32_t blk = w / 64u, l = w % 64u;
+    px = (int)(tx * P.tile + (blk % bpr) * 8u + (l % 8u));
+    py = (int)(ty * P.tile + (blk / bpr) * 8u + (l / 8u));
+    return px < C.width && py < C.height;
+}

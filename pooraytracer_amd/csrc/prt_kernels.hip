@@ -1,0 +1,362 @@
+// prt_kernels.hip — gfx950 kernels of the path-tracing hot path and their launchers.
+//
+//   K1 k_trace_closest   closest hit for a ray batch               (world.Hit, BVH.cpp:51-61)
+//   K3 k_render          persistent-wavefront path tracer          (Camera::Render/RayColor, Camera.cpp:21-204)
+//   K5 k_finalize        ordered sum of per-chunk partial sums -> f64 / f32 framebuffer
+//      k_sample_lights   lights.Sample test hook                   (BVH.cpp:62-67,86-100)
+//      k_tonemap         NaN scrub + sRGB + clamp -> u8            (Camera.cpp:206-221,279-301)
+//
+// K3 design (MI355X: 256 CUs x 4 SIMD, wave64, 160 KB LDS/CU, per-XCD L2):
+//   * persistent workgroups (grid = CUs x resident blocks); every LANE owns one work item =
+//     (pixel, sample chunk) and pulls the next one from a global atomic counter when it finishes, so
+//     short paths (light / background pixels) never idle a wave for long — lane-level regeneration
+//     instead of a per-bounce compaction pass;
+//   * one loop iteration = one path vertex: all lanes trace their continuation ray together, shade,
+//     then the lanes that sample lights trace their shadow ray together (closest-hit semantics with a
+//     certain-occluder early-out), then Russian roulette + Scatter produce the next ray;
+//   * traversal stack in LDS, lane-strided (conflict-free), PRT_STACK_DEPTH entries per lane;
+//   * results are deterministic: per-sample keyed RNG, per-item partial sums combined in a fixed
+//     order by K5 (no float atomics on the framebuffer).
+#include <hip/hip_runtime.h>
+
+#include "../../include/prt.h"
+#include "prt_device.h"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------- K1
+template <bool COUNT>
+__global__ __launch_bounds__(PRT_BLOCK) void k_trace_closest(DScene S, const PrtRay* __restrict__ rays, size_t n,
+                                                             PrtHit* __restrict__ hits, DCounters* ctr) {
+    __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* stk = &s_stack[wave][0][lane];
+    WorkCount wc{0, 0};
+    uint32_t nrays = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double4* rp = reinterpret_cast<const double4*>(rays + i);
+        double4 r0 = rp[0], r1 = rp[1];
+        d3 o = mk3(r0.x, r0.y, r0.z), d = mk3(r1.x, r1.y, r1.z);
+        HitInfo h;
+        if (S.n_tris == 0) {
+            h.t = r1.w;
+            h.tri = -1;
+            h.alpha = h.beta = 0;
+        } else {
+            trace<COUNT>(S, o, d, r0.w, r1.w, -PRT_INF, h, stk, wc);
+        }
+        nrays++;
+        PrtHit out;
+        if (h.tri >= 0) {
+            const DTri* T = S.tris + h.tri;
+            d3 nrm = mk3(T->n[0], T->n[1], T->n[2]);
+            out.t = h.t;
+            out.alpha = h.alpha;
+            out.beta = h.beta;
+            out.prim = S.shade[h.tri].prim;
+            out.front = dot(d, nrm) < 0. ? 1 : 0; // HitRecord::SetFaceNormal, Hittable.cpp:8-13
+        } else {
+            out.t = PRT_INF;
+            out.alpha = out.beta = 0;
+            out.prim = -1;
+            out.front = 0;
+        }
+        hits[i] = out;
+    }
+    unsigned long long a = wave_sum((unsigned long long)nrays);
+    unsigned long long b = wave_sum((unsigned long long)wc.nodes);
+    unsigned long long c = wave_sum((unsigned long long)wc.tris);
+    if (lane == 0) {
+        atomicAdd(&ctr->rays_closest, a);
+        if (COUNT) {
+            atomicAdd(&ctr->node_fetches, b);
+            atomicAdd(&ctr->tri_tests, c);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- K3
+enum : int { ST_FETCH = 0, ST_NEW_SAMPLE = 1, ST_TRACE = 2, ST_DONE = 3 };
+
+template <bool COUNT>
+__global__ __launch_bounds__(PRT_BLOCK) void k_render(DScene S, DCamera C, DRenderParams P, double* __restrict__ partial,
+                                                      DCounters* ctr) {
+    __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t* stk = &s_stack[wave][0][lane];
+
+    WorkCount wc{0, 0};
+    uint32_t n_closest = 0, n_shadow = 0, n_samples = 0;
+
+    int state = ST_FETCH;
+    uint64_t item = 0;
+    int px = 0, py = 0, s = 0, s_end = 0, depth = 0;
+    bool first = true, prev_skip = false;
+    d3 acc = mk3(0, 0, 0);  // sum over this item's samples of colour * (1/spp)
+    d3 L = mk3(0, 0, 0);    // radiance of the current sample
+    d3 beta = mk3(1, 1, 1); // path throughput
+    d3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
+    Rng rng;
+    rng.s = 0;
+    const double inv_spp = 1.0 / P.spp; // pixelSamplesScale, Camera.cpp:83
+    const d3 bg = ld3(P.background);
+
+    for (;;) {
+        if (state == ST_FETCH) {
+            item = atomicAdd(&ctr->next_item, 1ULL);
+            if (item >= P.n_items) {
+                state = ST_DONE;
+            } else {
+                const uint32_t chunk = (uint32_t)(item / P.items_per_chunk);
+                const uint64_t oi = item % P.items_per_chunk;
+                if (owned_to_pixel(P, C, oi, px, py)) {
+                    s = (int)(((int64_t)chunk * P.spp) / P.chunks);
+                    s_end = (int)(((int64_t)(chunk + 1) * P.spp) / P.chunks);
+                    acc = mk3(0, 0, 0);
+                    if (s < s_end) state = ST_NEW_SAMPLE;
+                    else {
+                        double* o = partial + item * 3;
+                        o[0] = o[1] = o[2] = 0.0;
+                    }
+                }
+            }
+        }
+        if (__ballot(state != ST_DONE) == 0ULL) break;
+
+        if (state == ST_NEW_SAMPLE) {
+            // per-sample stream keyed (seed, j*W+i, s); Camera::GetRay (Camera.cpp:108-117): pixel centre, no jitter
+            rng.seed(P.seed, (uint64_t)py * (uint64_t)C.width + (uint64_t)px, (uint64_t)s);
+            d3 ps = ld3(C.pixel00) + ((double)px) * ld3(C.du) + ((double)py) * ld3(C.dv);
+            ro = ld3(C.center);
+            rd = ps - ro;
+            L = mk3(0, 0, 0);
+            beta = mk3(1, 1, 1);
+            depth = P.max_depth;
+            first = true;
+            prev_skip = false;
+            n_samples++;
+            state = ST_TRACE;
+        }
+
+        if (state == ST_TRACE) {
+            bool end_sample = false;
+            HitInfo h;
+            n_closest++;
+            trace<COUNT>(S, ro, rd, 0.0001, PRT_INF, -PRT_INF, h, stk, wc); // Camera.cpp:125
+            if (h.tri < 0) {
+                // miss: background for the camera ray (Camera.cpp:127); with bSampleLights a bounce miss adds 0 (:187)
+                if (first || !P.sample_lights) L = L + beta * bg;
+                end_sample = true;
+            } else {
+                const DTriShade sh = S.shade[h.tri];
+                const DMaterial& m = S.materials[sh.material];
+                if (m.has_emission) {
+                    // Camera.cpp:129-132; via a bounce only after SkipLightSampling materials (:191-195)
+                    if (first || !P.sample_lights || prev_skip) L = L + beta * ld3(m.emission);
+                    end_sample = true;
+                } else {
+                    const DTri* T = S.tris + h.tri;
+                    const d3 gn = mk3(T->n[0], T->n[1], T->n[2]);
+                    const bool front = dot(rd, gn) < 0.;
+                    Frame f;
+                    f.n = front ? gn : -gn;
+                    f.t = ld3(sh.tangent);
+                    const d3 pos = ro + rd * h.t; // record.position = ray(t)
+                    d2 uv;                        // Triangle.cpp:111
+                    {
+                        const double w0 = 1. - h.alpha - h.beta;
+                        uv.x = w0 * sh.uv0[0] + h.alpha * sh.uv1[0] + h.beta * sh.uv2[0];
+                        uv.y = w0 * sh.uv0[1] + h.alpha * sh.uv1[1] + h.beta * sh.uv2[1];
+                    }
+                    // ---- next-event estimation, Camera.cpp:137-173
+                    if (P.sample_lights && S.n_lights > 0 && !m.skip_light_sampling) {
+                        const LightPick lp = sample_lights(S, pos, rng);
+                        const d3 toL = lp.pos - pos;
+                        const d3 ldir = normalize(toL);
+                        const double dist = length(toL);
+                        if (dot(f.n, ldir) > 0.0 && lp.front) {
+                            // visibility = closest hit along the shadow ray no nearer than dist-1e-3 (:150-155)
+                            HitInfo sh_hit;
+                            n_shadow++;
+                            trace<COUNT>(S, pos, ldir, 0.001, 1.7976931348623157e308, dist - 0.001 - 1e-6, sh_hit, stk, wc);
+                            bool visible = true; // an escaping shadow ray counts as unoccluded
+                            if (sh_hit.tri >= 0) {
+                                const d3 pn = pos + ldir * sh_hit.t;
+                                visible = (dist - length(pos - pn)) < 0.001;
+                            }
+                            if (visible) {
+                                const DLightTri* lt = S.light_tris + lp.tri;
+                                const d3 emission = ld3(S.materials[lt->material].emission);
+                                const d3 wo = world_to_local(-rd, f);
+                                const d3 lwi = world_to_local(ldir, f);
+                                const d3 lln = world_to_local(lp.n, f);
+                                const d3 fr = mat_eval(S, m, lwi, wo, uv, rng);
+                                const double cosT = lwi.z;
+                                const double cosTB = dot(lln, -lwi);
+                                const d3 direct = emission * fr * cosT * cosTB / (dist * dist) / lp.pdf;
+                                L = L + beta * direct;
+                            }
+                        }
+                    }
+                    // ---- Russian roulette + Scatter, Camera.cpp:176-202
+                    end_sample = true;
+                    if (rng.next() < P.rr) {
+                        d3 att, wi;
+                        if (mat_scatter(S, m, rd, f, uv, rng, att, wi)) {
+                            depth--; // RayColor(scattered, depth-1): returns 0 when depth-1 < 0
+                            if (depth >= 0) {
+                                beta = beta * att / P.rr;
+                                // a zero throughput (Phong bad sample) contributes exactly 0 from here on
+                                if (!(beta.x == 0. && beta.y == 0. && beta.z == 0.)) {
+                                    ro = pos;
+                                    rd = wi;
+                                    prev_skip = m.skip_light_sampling != 0;
+                                    first = false;
+                                    end_sample = false;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (end_sample) {
+                acc = acc + L * inv_spp; // colorAttachment[m] += RayColor(...) * pixelSamplesScale (Camera.cpp:56)
+                s++;
+                if (s < s_end) state = ST_NEW_SAMPLE;
+                else {
+                    double* o = partial + item * 3;
+                    o[0] = acc.x;
+                    o[1] = acc.y;
+                    o[2] = acc.z;
+                    state = ST_FETCH;
+                }
+            }
+        }
+    }
+
+    unsigned long long a = wave_sum((unsigned long long)n_closest);
+    unsigned long long b = wave_sum((unsigned long long)n_shadow);
+    unsigned long long c = wave_sum((unsigned long long)n_samples);
+    unsigned long long d = wave_sum((unsigned long long)wc.nodes);
+    unsigned long long e = wave_sum((unsigned long long)wc.tris);
+    if (lane == 0) {
+        atomicAdd(&ctr->rays_closest, a);
+        atomicAdd(&ctr->rays_shadow, b);
+        atomicAdd(&ctr->samples, c);
+        if (COUNT) {
+            atomicAdd(&ctr->node_fetches, d);
+            atomicAdd(&ctr->tri_tests, e);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- K5
+// out[pixel] = sum over chunks (fixed order) of the item partial sums; pixels of other ranks' tiles
+// were zeroed by a memset so that the cross-rank sum is exact.
+__global__ void k_finalize(DCamera C, DRenderParams P, const double* __restrict__ partial, double* __restrict__ out64,
+                           float* __restrict__ out32) {
+    const uint64_t oi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (oi >= P.items_per_chunk) return;
+    int px, py;
+    if (!owned_to_pixel(P, C, oi, px, py)) return;
+    double r = 0, g = 0, b = 0;
+    for (int c = 0; c < P.chunks; ++c) {
+        const double* p = partial + ((uint64_t)c * P.items_per_chunk + oi) * 3;
+        r += p[0];
+        g += p[1];
+        b += p[2];
+    }
+    const size_t m = ((size_t)py * C.width + px) * 3;
+    if (out64) {
+        out64[m] = r;
+        out64[m + 1] = g;
+        out64[m + 2] = b;
+    }
+    if (out32) {
+        out32[m] = (float)r;
+        out32[m + 1] = (float)g;
+        out32[m + 2] = (float)b;
+    }
+}
+
+__global__ void k_sample_lights(DScene S, const double* __restrict__ origins, size_t n, uint64_t seed,
+                                PrtLightSample* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng rng;
+    rng.seed(seed, i, 0);
+    const LightPick lp = sample_lights(S, mk3(origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2]), rng);
+    PrtLightSample o;
+    o.position[0] = lp.pos.x; o.position[1] = lp.pos.y; o.position[2] = lp.pos.z;
+    o.normal[0] = lp.n.x; o.normal[1] = lp.n.y; o.normal[2] = lp.n.z;
+    o.pdf = lp.pdf;
+    o.prim = S.light_tris[lp.tri].prim;
+    o.front = lp.front ? 1 : 0;
+    out[i] = o;
+}
+
+// Camera::WriteColorAttachment's per-pixel transform (Camera.cpp:279-301): NaN -> 0, LinearToSRGB
+// (:214-221), clamp to [0, 0.9999], * 255 truncated to uint8.
+__global__ void k_tonemap(const float* __restrict__ in, size_t n, uint8_t* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = (double)in[i];
+    if (v != v) v = 0.0;
+    double sv = (v <= 0.0031308) ? 12.92 * v : 1.055 * pow(v, (1. / 2.4)) - 0.055;
+    sv = sv < 0.0 ? 0.0 : (sv > 0.9999 ? 0.9999 : sv);
+    out[i] = (uint8_t)(sv * 255);
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------- launchers
+namespace prt {
+
+int render_blocks_per_cu(bool count) {
+    int nb = 0;
+    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render<true>, PRT_BLOCK, 0)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render<false>, PRT_BLOCK, 0);
+    if (e != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
+void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hits, DCounters* d_ctr, bool count,
+                  int n_cu, hipStream_t st) {
+    if (n == 0) return;
+    size_t want = (n + PRT_BLOCK - 1) / PRT_BLOCK;
+    unsigned grid = (unsigned)std::min<size_t>(want, (size_t)n_cu * 8);
+    if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(PRT_BLOCK), 0, st, S, d_rays, n, d_hits, d_ctr);
+    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(PRT_BLOCK), 0, st, S, d_rays, n, d_hits, d_ctr);
+}
+
+void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
+                   bool count, unsigned grid, hipStream_t st) {
+    if (count) hipLaunchKernelGGL(k_render<true>, dim3(grid), dim3(PRT_BLOCK), 0, st, S, C, P, d_partial, d_ctr);
+    else hipLaunchKernelGGL(k_render<false>, dim3(grid), dim3(PRT_BLOCK), 0, st, S, C, P, d_partial, d_ctr);
+}
+
+void launch_finalize(const DCamera& C, const DRenderParams& P, const double* d_partial, double* d64, float* d32,
+                     hipStream_t st) {
+    unsigned grid = (unsigned)((P.items_per_chunk + 255) / 256);
+    if (grid == 0) return;
+    hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, st, C, P, d_partial, d64, d32);
+}
+
+void launch_sample_lights(const DScene& S, const double* d_origins, size_t n, uint64_t seed, PrtLightSample* d_out,
+                          hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_sample_lights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, d_origins, n, seed, d_out);
+}
+
+void launch_tonemap(const float* d_in, size_t n, uint8_t* d_out, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, n, d_out);
+}
+
+} // namespace prt

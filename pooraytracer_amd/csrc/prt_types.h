@@ -1,0 +1,113 @@
+// prt_types.h — device-resident data layouts shared by the host builder and the HIP kernels.
+//
+// HBM layout (all arrays are plain hipMalloc allocations, 128-byte aligned):
+//   DNode   [n_nodes]   64 B  BVH2 inner node: both children's boxes as fp32 rounded OUTWARD
+//                             (conservative cull only; every accept/reject of a hit is fp64) + 2 refs
+//   DTri    [n_tris]   128 B  fp64 intersection record in BVH leaf order (Triangle.cpp:54-83 inputs)
+//   DTriShade[n_tris]   96 B  fp64 shading record in the same order (tangent, texcoords, material)
+//   DMaterial[n_mat]          material table (Material.h parameters)
+//   DLightNode/DLightTri      the reference's area-CDF light tree (BVH.cpp:86-100), exact fp64 areas
+//   texels / DTexture         8-bit texels + descriptors, 256-entry sRGB->linear LUT
+#pragma once
+#include <stdint.h>
+
+#define PRT_STACK_DEPTH 32   // LDS traversal stack entries per lane; builder bounds tree depth to it
+#define PRT_LEAF_MAX 4       // triangles per BVH leaf (leaf ref stores count-1 in 3 bits)
+#define PRT_BLOCK 256        // threads per workgroup (4 wave64)
+
+struct alignas(64) DNode {
+    // (lo,hi) pairs per axis so one 16-byte load feeds one axis of one child
+    float c0x[2], c0y[2], c0z[2]; // child 0: {lo,hi} x,y,z
+    float c1x[2], c1y[2], c1z[2]; // child 1
+    int32_t ref0, ref1;           // >=0: inner node index; <0: leaf, ~ref = (first_tri << 3) | (count-1)
+    int32_t pad[2];
+};
+static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
+
+struct alignas(128) DTri {
+    double n[3];   // unit geometric normal        (Triangle.cpp:19)
+    double D;      // dot(normal, v0)              (Triangle.cpp:50)
+    double w[3];   // n / dot(n,n), n = e0 x e1    (Triangle.cpp:51)
+    double v0[3];
+    double e0[3];  // v1 - v0
+    double e1[3];  // v2 - v0
+};
+static_assert(sizeof(DTri) == 128, "DTri must be 128 bytes");
+
+struct alignas(32) DTriShade {
+    double tangent[3]; // Triangle.cpp:31-46
+    double uv0[2], uv1[2], uv2[2];
+    int32_t material;
+    int32_t prim;      // index in PrtSceneDesc order
+    double pad[2];
+};
+static_assert(sizeof(DTriShade) == 96, "DTriShade must be 96 bytes");
+
+struct DMaterial {
+    int32_t type;
+    int32_t texture;
+    double kd[3], ks[3];
+    double ns, pkd, pks;
+    double emission[3]; // GetEmission(): DiffuseLight radiance / Debug albedo
+    double eta[3], k[3];
+    double alpha_x, alpha_y;
+    int32_t has_emission, skip_light_sampling;
+};
+
+struct DTexture {
+    int32_t width, height, channels, has_data;
+    uint64_t offset; // byte offset into the texel blob
+};
+
+struct DLightNode {
+    double left_area;   // GetArea() of the left child (BVH.cpp:93-97)
+    int32_t left, right; // >=0 node, <0: ~index into light tris
+};
+
+struct alignas(128) DLightTri {
+    double v0[3], v1[3], v2[3];
+    double n[3];
+    double area;
+    int32_t material, prim;
+    double pad[2];
+};
+static_assert(sizeof(DLightTri) == 128, "DLightTri must be 128 bytes");
+
+struct DScene {
+    const DNode* nodes;
+    const DTri* tris;
+    const DTriShade* shade;
+    const DMaterial* materials;
+    const DTexture* textures;
+    const uint8_t* texels;
+    const double* srgb_lut; // [256] SRGBToLinear(b/255) (Texture.cpp:66-70), computed on the host with std::pow
+    const DLightNode* light_nodes;
+    const DLightTri* light_tris;
+    int32_t light_root; // ref into light tree; valid iff n_lights > 0
+    int32_t n_lights;
+    double light_area;  // GetArea() of the top-level lights BVHNode
+    uint32_t n_nodes, n_tris;
+};
+
+// camera state after Camera::Initialize (Camera.cpp:75-106), computed on the host
+struct DCamera {
+    double center[3], pixel00[3], du[3], dv[3];
+    int32_t width, height;
+};
+
+struct DRenderParams {
+    int32_t spp, max_depth, sample_lights, chunks;
+    double rr;
+    double background[3];
+    uint64_t seed;
+    int32_t tile, tiles_x, tiles_y, n_tiles;
+    int32_t rank, nranks, owned_tiles, pad;
+    uint64_t items_per_chunk; // owned_tiles * tile * tile
+    uint64_t n_items;         // items_per_chunk * chunks
+};
+
+// device-side counters, zeroed before each call
+struct DCounters {
+    unsigned long long next_item;
+    unsigned long long rays_closest, rays_shadow, node_fetches, tri_tests, samples;
+};

@@ -1,0 +1,280 @@
+// scene_setup.cpp — host-side scene preparation: per-triangle precompute, material table, the
+// reference-ordered light tree and the camera frame.  Pure host C++ (no device code); runs once per
+// scene / per frame, never per ray.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "prt_host.h"
+
+namespace prt {
+namespace {
+
+struct V {
+    double x, y, z;
+};
+inline V sub(V a, V b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V add(V a, V b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V scale(V a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+inline double dot(V a, V b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V cross(V a, V b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y}; }
+inline V unit(V a) { return scale(a, 1.0 / std::sqrt(dot(a, a))); } // glm::normalize
+inline bool has_nan(V a) { return a.x != a.x || a.y != a.y || a.z != a.z; }
+inline void store(double* p, V a) {
+    p[0] = a.x;
+    p[1] = a.y;
+    p[2] = a.z;
+}
+inline V load(const double* p) { return {p[0], p[1], p[2]}; }
+
+// AABB(a,b) + PadToMinimus per axis (AABB.cpp:16-22,76-82), then the union of the two edge boxes
+// (Triangle.cpp:94-99).  The pad is applied to each edge box before the union, as in the reference.
+inline void edge_interval(double a, double b, double& lo, double& hi) {
+    lo = (a <= b) ? a : b;
+    hi = (a <= b) ? b : a;
+    if (hi - lo < 0.0001) {
+        lo -= 0.0001 / 2.;
+        hi += 0.0001 / 2.;
+    }
+}
+
+} // namespace
+
+void setup_triangles(const PrtSceneDesc& d, std::vector<HostTri>& out) {
+    out.resize(d.n_tris);
+    for (uint32_t m = 0; m < d.n_meshes; ++m) {
+        for (uint64_t t = d.mesh_first_tri[m]; t < d.mesh_first_tri[m + 1]; ++t) {
+            HostTri& T = out[t];
+            V p[3], vn[3];
+            for (int k = 0; k < 3; ++k) {
+                p[k] = load(d.vertices + t * 9 + k * 3);
+                vn[k] = d.normals ? load(d.normals + t * 9 + k * 3) : V{0, 0, 0};
+                T.uv[k][0] = d.texcoords ? d.texcoords[t * 6 + k * 2] : 0.0;
+                T.uv[k][1] = d.texcoords ? d.texcoords[t * 6 + k * 2 + 1] : 0.0;
+                store(T.v[k], p[k]);
+            }
+            T.material = d.mesh_material[m];
+            T.prim = (int32_t)t;
+            V e0 = sub(p[1], p[0]), e1 = sub(p[2], p[0]);
+            V n = cross(e0, e1);
+            V nn = unit(n);
+            if (has_nan(nn)) { // degenerate face: vertex-normal fallback, then +z (Triangle.cpp:21-29)
+                nn = unit(add(add(vn[0], vn[1]), vn[2]));
+                if (has_nan(nn)) nn = V{0.0, 0.0, 1.0};
+            }
+            // tangent from the UV deltas (Triangle.cpp:31-37)
+            double du0 = T.uv[1][0] - T.uv[0][0], dv0 = T.uv[1][1] - T.uv[0][1];
+            double du1 = T.uv[2][0] - T.uv[0][0], dv1 = T.uv[2][1] - T.uv[0][1];
+            double f = 1.0 / (du0 * dv1 - du1 * dv0);
+            V tg{f * (dv1 * e0.x - dv0 * e1.x), f * (dv1 * e0.y - dv0 * e1.y), f * (dv1 * e0.z - dv0 * e1.z)};
+            tg = unit(tg);
+            if (has_nan(tg)) { // Triangle.cpp:39-46 (0.9f: float literal)
+                V helper = (std::fabs(nn.x) < (double)0.9f) ? V{1, 0, 0} : V{0, 1, 0};
+                tg = unit(cross(nn, helper));
+            }
+            store(T.e0, e0);
+            store(T.e1, e1);
+            store(T.normal, nn);
+            store(T.tangent, tg);
+            T.area = std::sqrt(dot(n, n)) * 0.5;
+            T.D = dot(nn, p[0]);
+            double nn2 = dot(n, n);
+            T.w[0] = n.x / nn2;
+            T.w[1] = n.y / nn2;
+            T.w[2] = n.z / nn2;
+            for (int a = 0; a < 3; ++a) {
+                double l0, h0, l1, h1;
+                edge_interval(T.v[0][a], T.v[1][a], l0, h0);
+                edge_interval(T.v[0][a], T.v[2][a], l1, h1);
+                T.lo[a] = l0 <= l1 ? l0 : l1;
+                T.hi[a] = h0 >= h1 ? h0 : h1;
+            }
+        }
+    }
+}
+
+void setup_materials(const PrtSceneDesc& d, std::vector<DMaterial>& out) {
+    out.resize(d.n_materials);
+    for (uint32_t i = 0; i < d.n_materials; ++i) {
+        const PrtMaterial& s = d.materials[i];
+        DMaterial& m = out[i];
+        std::memset(&m, 0, sizeof(m));
+        m.type = s.type;
+        m.texture = s.texture;
+        for (int c = 0; c < 3; ++c) {
+            m.kd[c] = s.kd[c];
+            m.ks[c] = s.ks[c];
+            m.eta[c] = s.eta[c];
+            m.k[c] = s.k[c];
+        }
+        m.ns = s.ns;
+        // SetProbabilitiesByNs, Material.h:318-327
+        if (s.ns <= 9.) {
+            m.pkd = 1.0;
+            m.pks = 0.0;
+        } else {
+            m.pkd = 0.6;
+            m.pks = 0.4;
+        }
+        m.alpha_x = s.alpha_x;
+        m.alpha_y = s.alpha_y;
+        m.has_emission = (s.type == PRT_MAT_DIFFUSE_LIGHT || s.type == PRT_MAT_DEBUG) ? 1 : 0; // Material.h:168,527
+        for (int c = 0; c < 3; ++c)
+            m.emission[c] = s.type == PRT_MAT_DIFFUSE_LIGHT ? s.emission[c] : (s.type == PRT_MAT_DEBUG ? s.kd[c] : 0.0);
+        // SkipLightSampling: Material.h:73 (false), :328 Phong Ns>1, :365 mirror, :539 empty
+        m.skip_light_sampling =
+            (s.type == PRT_MAT_MIRROR || s.type == PRT_MAT_EMPTY || (s.type == PRT_MAT_PHONG && s.ns > 1.)) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Light tree.  NEE picks a light triangle by descending the reference's lights BVH with an area
+// CDF (BVH.cpp:86-100); which triangle a given `p` lands on therefore depends on that tree's shape:
+// a two-level median-split build (main.cpp:36-45 -> BVH.cpp:7-48) whose std::sort reorders each
+// mesh's triangle list in place.  For an emissive mesh the list is sorted once by the world build
+// (main.cpp:39) and then again by the lights build (main.cpp:41); both passes are replayed here so
+// the leaf order is the reference's.  Only emissive meshes are touched (tiny), never the world.
+namespace {
+
+struct Obj { // a Hittable handle: triangle (node < 0) or tree node
+    int32_t tri;  // index into HostTri when node < 0
+    int32_t node; // index into TNode otherwise
+};
+struct TNode {
+    double lo[3], hi[3];
+    double area;
+    Obj left, right;
+    bool single; // span-1 node: left == right
+};
+
+struct RefBuilder {
+    const std::vector<HostTri>& tris;
+    std::vector<TNode> nodes;
+    explicit RefBuilder(const std::vector<HostTri>& t) : tris(t) {}
+
+    const double* lo(const Obj& o) const { return o.node < 0 ? tris[o.tri].lo : nodes[o.node].lo; }
+    const double* hi(const Obj& o) const { return o.node < 0 ? tris[o.tri].hi : nodes[o.node].hi; }
+    double area(const Obj& o) const { return o.node < 0 ? tris[o.tri].area : nodes[o.node].area; }
+
+    int32_t build(std::vector<Obj>& objs, size_t start, size_t end) { // BVH.cpp:7-48
+        TNode n;
+        const double inf = std::numeric_limits<double>::infinity();
+        for (int a = 0; a < 3; ++a) {
+            n.lo[a] = inf;
+            n.hi[a] = -inf;
+        }
+        for (size_t i = start; i < end; ++i)
+            for (int a = 0; a < 3; ++a) {
+                const double l = lo(objs[i])[a], h = hi(objs[i])[a];
+                n.lo[a] = n.lo[a] <= l ? n.lo[a] : l; // Interval(a,b) union, Interval.h:14-17
+                n.hi[a] = n.hi[a] >= h ? n.hi[a] : h;
+            }
+        const double lx = n.hi[0] - n.lo[0], ly = n.hi[1] - n.lo[1], lz = n.hi[2] - n.lo[2];
+        const int axis = (lx > ly) ? (lx > lz ? 0 : 2) : (ly > lz ? 1 : 2); // AABB.cpp:66-74
+        const size_t span = end - start;
+        n.single = false;
+        if (span == 1) {
+            n.left = n.right = objs[start];
+            n.area = area(objs[start]);
+            n.single = true;
+        } else if (span == 2) {
+            n.left = objs[start];
+            n.right = objs[start + 1];
+            n.area = area(objs[start]) + area(objs[start + 1]);
+        } else {
+            std::sort(objs.begin() + start, objs.begin() + end,
+                      [&](const Obj& a, const Obj& b) { return lo(a)[axis] < lo(b)[axis]; });
+            const size_t mid = start + span / 2;
+            const int32_t l = build(objs, start, mid);
+            const int32_t r = build(objs, mid, end);
+            n.left = Obj{-1, l};
+            n.right = Obj{-1, r};
+            n.area = nodes[l].area + nodes[r].area;
+        }
+        nodes.push_back(n);
+        return (int32_t)nodes.size() - 1;
+    }
+};
+
+int32_t flatten_light(const RefBuilder& rb, const Obj& o, LightTree& out, const std::vector<HostTri>& tris) {
+    if (o.node < 0) {
+        const HostTri& T = tris[o.tri];
+        DLightTri lt;
+        std::memset(&lt, 0, sizeof(lt));
+        std::memcpy(lt.v0, T.v[0], 24);
+        std::memcpy(lt.v1, T.v[1], 24);
+        std::memcpy(lt.v2, T.v[2], 24);
+        std::memcpy(lt.n, T.normal, 24);
+        lt.area = T.area;
+        lt.material = T.material;
+        lt.prim = T.prim;
+        out.tris.push_back(lt);
+        return ~(int32_t)(out.tris.size() - 1);
+    }
+    const TNode& n = rb.nodes[o.node];
+    if (n.single) return flatten_light(rb, n.left, out, tris); // both branches reach the same child
+    const int32_t idx = (int32_t)out.nodes.size();
+    out.nodes.push_back(DLightNode{rb.area(n.left), 0, 0});
+    const int32_t l = flatten_light(rb, n.left, out, tris);
+    const int32_t r = flatten_light(rb, n.right, out, tris);
+    out.nodes[idx].left = l;
+    out.nodes[idx].right = r;
+    return idx;
+}
+
+} // namespace
+
+void build_light_tree(const PrtSceneDesc& d, const std::vector<HostTri>& tris, const std::vector<DMaterial>& mats,
+                      LightTree& out) {
+    out.nodes.clear();
+    out.tris.clear();
+    out.root = -1;
+    out.area = 0.0;
+    RefBuilder rb(tris);
+    std::vector<Obj> lights;
+    for (uint32_t m = 0; m < d.n_meshes; ++m) {
+        if (!mats[d.mesh_material[m]].has_emission) continue;
+        std::vector<Obj> objs;
+        for (uint64_t t = d.mesh_first_tri[m]; t < d.mesh_first_tri[m + 1]; ++t) objs.push_back(Obj{(int32_t)t, -1});
+        if (objs.empty()) continue;
+        rb.build(objs, 0, objs.size());                               // world.Add(BVHNode(mesh))  main.cpp:39
+        lights.push_back(Obj{-1, rb.build(objs, 0, objs.size())});    // lights.Add(BVHNode(mesh)) main.cpp:41
+    }
+    if (lights.empty()) return;
+    const int32_t top = rb.build(lights, 0, lights.size()); // lights = HittableList(BVHNode(lights)) main.cpp:45
+    out.area = rb.nodes[top].area;
+    out.root = flatten_light(rb, Obj{-1, top}, out, tris);
+}
+
+void setup_camera(const PrtCamera& c, DCamera& out) { // Camera.cpp:75-106
+    const int W = c.width < 1 ? 1 : c.width, H = c.height < 1 ? 1 : c.height;
+    const double aspect = double(W) / double(H);
+    V eye = load(c.eye), look = load(c.look_at), up = load(c.up);
+    V el = sub(eye, look);
+    const double focal = std::sqrt(dot(el, el));
+    const double theta = c.fovy * 0.01745329251994329576923690768489; // glm::radians
+    const double h = std::tan(theta / 2.0);
+    const double vh = 2. * h * focal;
+    const double vw = vh * aspect;
+    V w = unit(el);
+    V u = unit(cross(up, w));
+    V v = cross(w, u);
+    V vu{vw * u.x, vw * u.y, vw * u.z};
+    V nv{-v.x, -v.y, -v.z};
+    V vv{vh * nv.x, vh * nv.y, vh * nv.z};
+    V du{vu.x / (double)W, vu.y / (double)W, vu.z / (double)W};
+    V dv{vv.x / (double)H, vv.y / (double)H, vv.z / (double)H};
+    V fw{focal * w.x, focal * w.y, focal * w.z};
+    V ul = sub(sub(sub(eye, fw), V{vu.x / 2., vu.y / 2., vu.z / 2.}), V{vv.x / 2., vv.y / 2., vv.z / 2.});
+    V s = add(du, dv);
+    V p00 = add(ul, V{0.5 * s.x, 0.5 * s.y, 0.5 * s.z});
+    store(out.center, eye);
+    store(out.pixel00, p00);
+    store(out.du, du);
+    store(out.dv, dv);
+    out.width = W;
+    out.height = H;
+}
+
+} // namespace prt

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def prt_lib():
+    """libprt_hip.so, built in-tree if stale (hipcc cross-compiles without a GPU)."""
+    from pooraytracer_amd import api, build
+    build.build()
+    return api.load()
+
+
+@pytest.fixture(scope="session")
+def gpu(prt_lib):
+    from pooraytracer_amd import api
+    if api.device_count() < 1:
+        pytest.fail("no HIP device visible: -m gpu tests need a real GPU (there is no CPU fallback)")
+    return 0

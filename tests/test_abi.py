@@ -1,0 +1,79 @@
+"""C-ABI surface: the library loads, exports every symbol include/prt.h declares, struct layouts
+agree between prt.h, _abi.py and the oracle header, and host-only entry points work without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from pooraytracer_amd import _abi, api, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_all_exported(prt_lib):
+    hdr = open(os.path.join(ROOT, "include", "prt.h")).read()
+    declared = set(re.findall(r"\b(prt_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_abi.EXPORTS), declared ^ set(_abi.EXPORTS)
+    for name in declared:
+        assert hasattr(prt_lib, name), f"{name} not exported by libprt_hip.so"
+    assert prt_lib.prt_abi_version() == _abi.PRT_ABI_VERSION
+
+
+def test_struct_layouts_match_header(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "prt.h"\n#include "oracle.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+        "sizeof(PrtMaterial),sizeof(PrtTexture),sizeof(PrtSceneDesc),sizeof(PrtCamera),sizeof(PrtRenderParams),"
+        "sizeof(PrtRay),sizeof(PrtHit),sizeof(PrtLightSample),sizeof(PrtCounters));"
+        'printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",sizeof(OrcMaterial),sizeof(OrcTexture),sizeof(OrcSceneDesc),'
+        "sizeof(OrcCamera),sizeof(OrcRenderParams),sizeof(OrcRay),sizeof(OrcHit),sizeof(OrcLightSample));return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "oracle"), str(src), "-o", str(exe)])
+    a, b = subprocess.check_output([str(exe)]).decode().strip().split("\n")
+    prt_sizes = [int(x) for x in a.split()]
+    orc_sizes = [int(x) for x in b.split()]
+    py = [C.sizeof(t) for t in (_abi.PrtMaterial, _abi.PrtTexture, _abi.PrtSceneDesc, _abi.PrtCamera,
+                                _abi.PrtRenderParams, _abi.PrtRay, _abi.PrtHit, _abi.PrtLightSample, _abi.PrtCounters)]
+    assert prt_sizes == py
+    assert orc_sizes == py[:8]
+
+
+def test_scene_create_and_light_order_without_gpu(prt_lib):
+    sc = api.Scene(scenes.tiny_scene())
+    order = sc.light_order()
+    assert sorted(order.tolist()) == [10, 11]  # the two triangles of the ceiling light quad
+    cnt = sc.counters()
+    assert cnt["bvh_nodes"] >= 1 and cnt["bvh_depth"] <= 30
+    sc.close()
+
+
+def test_compute_fails_loudly_without_upload(prt_lib):
+    sc = api.Scene(scenes.tiny_scene())
+    rays = scenes.random_rays(4, (-1, -1, -1), (1, 1, 1))
+    with pytest.raises(api.PrtError) as e:
+        sc.trace_closest(rays)
+    assert e.value.code == _abi.PRT_E_NO_DEVICE
+    with pytest.raises(api.PrtError):
+        sc.render(spp=1)
+
+
+def test_scene_create_rejects_bad_input(prt_lib):
+    data = scenes.tiny_scene()
+    data.mesh_material = data.mesh_material.copy()
+    data.mesh_material[0] = 99
+    with pytest.raises(api.PrtError) as e:
+        api.Scene(data)
+    assert e.value.code == _abi.PRT_E_INVALID
+
+
+def test_product_does_not_import_oracle():
+    """The product package and C sources must never reference the oracle."""
+    pkg = os.path.join(ROOT, "pooraytracer_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "oracle.h" not in txt, f

@@ -1,0 +1,170 @@
+"""CPU tests of the oracle (the restated reference algorithm): hand-derived known answers,
+invariants and the committed golden fixtures.  PARITY UNPINNED: the reference ships no vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from pooraytracer_amd import _abi, scenes
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def one_triangle(material=None):
+    b = scenes._Builder("one")
+    m = b.material(material or scenes.Material("DiffuseWhite", _abi.MAT_LAMBERTIAN, kd=(0.5, 0.5, 0.5)))
+    v = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], dtype=np.float64)
+    uv = np.array([[[0, 0], [1, 0], [0, 1]]], dtype=np.float64)
+    b.mesh("t", m, v, uv)
+    return b.build(scenes.Camera(4, 4, 30.0, (0.25, 0.25, 2.0), (0.25, 0.25, 0.0)))
+
+
+def mkrays(o, d, tmin=1e-4, tmax=np.inf):
+    o = np.atleast_2d(np.asarray(o, dtype=np.float64))
+    d = np.atleast_2d(np.asarray(d, dtype=np.float64))
+    r = np.zeros(o.shape[0], dtype=_abi.RAY_DTYPE)
+    r["o"], r["d"], r["tmin"], r["tmax"] = o, d, tmin, tmax
+    return r
+
+
+def test_triangle_hit_known_answers():
+    """Triangle::Hit (Triangle.cpp:54-83): t, barycentrics, face flag, inclusive interval, parallel reject."""
+    o = oracle.Oracle(one_triangle())
+    h = o.trace_closest(mkrays([[0.25, 0.25, 2.0]], [[0, 0, -1]]))
+    assert h["prim"][0] == 0 and h["t"][0] == 2.0 and h["alpha"][0] == 0.25 and h["beta"][0] == 0.25 and h["front"][0] == 1
+    # unnormalised direction: t is in units of |d|
+    h = o.trace_closest(mkrays([[0.25, 0.25, 2.0]], [[0, 0, -4]]))
+    assert h["t"][0] == 0.5
+    # from behind: back face
+    h = o.trace_closest(mkrays([[0.25, 0.25, -1.0]], [[0, 0, 1]]))
+    assert h["prim"][0] == 0 and h["front"][0] == 0
+    # outside the triangle (alpha+beta > 1), and parallel ray (|n.d| < 1e-8)
+    h = o.trace_closest(mkrays([[0.75, 0.75, 2.0], [0.25, 0.25, 1.0]], [[0, 0, -1], [1, 0, 0]]))
+    assert (h["prim"] == -1).all() and np.isinf(h["t"]).all()
+    # inclusive interval (Interval.h:21-23): t == tmax and t == tmin are hits, just outside is not
+    h = o.trace_closest(mkrays([[0.25, 0.25, 2.0]] * 3, [[0, 0, -1]] * 3, tmin=[1e-4, 2.0, 2.0000001], tmax=[2.0, 5.0, 5.0]))
+    assert h["prim"].tolist() == [0, 0, -1]
+    # edge/vertex hits are accepted (alpha == 0 or beta == 0)
+    h = o.trace_closest(mkrays([[0.5, 0.0, 1.0], [0.0, 0.0, 1.0]], [[0, 0, -1]] * 2))
+    assert h["prim"].tolist() == [0, 0]
+
+
+def test_closest_of_many_is_minimum_t():
+    sc = scenes.tiny_scene()
+    o = oracle.Oracle(sc)
+    lo, hi = sc.bounds()
+    rays = scenes.random_rays(2000, lo, hi, seed=3)
+    h = o.trace_closest(rays)
+    # brute force in numpy over all triangles with the same formulas
+    v = sc.vertices
+    e0, e1 = v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
+    n = np.cross(e0, e1)
+    nn = n / np.linalg.norm(n, axis=1, keepdims=True)
+    D = (nn * v[:, 0]).sum(1)
+    w = n / (n * n).sum(1, keepdims=True)
+    for i in range(0, 2000, 37):
+        oo, dd = rays["o"][i], rays["d"][i]
+        den = nn @ dd
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (D - nn @ oo) / den
+        p = oo + dd * t[:, None]
+        v0p = p - v[:, 0]
+        al = (w * np.cross(v0p, e1)).sum(1)
+        be = (w * np.cross(e0, v0p)).sum(1)
+        ok = (np.abs(den) >= 1e-8) & (t >= 1e-4) & (al >= 0) & (be >= 0) & (al + be <= 1)
+        if ok.any():
+            tt = np.where(ok, t, np.inf)
+            assert h["prim"][i] >= 0 and abs(h["t"][i] - tt.min()) <= 1e-12 * max(1, tt.min())
+        else:
+            assert h["prim"][i] == -1
+
+
+def test_rng_stream_properties():
+    """Keyed RNG: 31-bit granularity like rand()/(RAND_MAX+1.0), in [0,1), keyed independence."""
+    a = oracle.rng_stream(1, 5, 7, 4096)
+    assert (a >= 0).all() and (a < 1).all()
+    assert np.array_equal(a * 2147483648.0, np.floor(a * 2147483648.0))
+    assert abs(a.mean() - 0.5) < 0.03
+    b = oracle.rng_stream(1, 5, 8, 4096)
+    c = oracle.rng_stream(2, 5, 7, 4096)
+    assert not np.array_equal(a, b) and not np.array_equal(a, c)
+    assert np.array_equal(a, oracle.rng_stream(1, 5, 7, 4096))
+
+
+def test_camera_rays_pinhole():
+    """Camera::Initialize/GetRay (Camera.cpp:75-117): pixel-centre rays, unnormalised, symmetric."""
+    cam = scenes.Camera(8, 4, 90.0, (0, 0, 0), (0, 0, -1))
+    r = oracle.camera_rays(cam)
+    assert np.allclose(r[..., :3], 0)
+    d = r[..., 3:]
+    assert np.allclose(d[..., 2], -1.0)  # focal length 1
+    # fovy 90 => viewport height 2, width 4; pixel (0,0) centre = (-2+0.25, 1-0.25)
+    assert np.allclose(d[0, 0, :2], [-1.75, 0.75])
+    assert np.allclose(d[3, 7, :2], [1.75, -0.75])
+    assert np.allclose(d[:, :, 0], -d[:, ::-1, 0]) and np.allclose(d[:, :, 1], -d[::-1, :, 1])
+
+
+def test_light_sampling_pdf_and_skew():
+    """lights.Sample: pdf = 1/total area; points lie on light triangles; sqrt-skewed pick (BVH.cpp:64)."""
+    sc = scenes.tiny_scene()
+    o = oracle.Oracle(sc)
+    org = np.zeros((20000, 3))
+    s = o.sample_lights(org, seed=9)
+    assert np.allclose(s["pdf"], 1.0 / 0.25)  # 0.5 x 0.5 quad
+    assert np.allclose(s["position"][:, 1], 0.998)
+    assert (np.abs(s["position"][:, [0, 2]]) <= 0.25 + 1e-12).all()
+    assert (s["front"] == 1).all() and np.allclose(s["normal"], [0, -1, 0])
+    order = o.light_order()
+    # p = sqrt(xi)*A: P(first leaf) = P(sqrt(xi) < 1/2) = 1/4 for two equal-area triangles
+    frac_first = (s["prim"] == order[0]).mean()
+    assert abs(frac_first - 0.25) < 0.02
+
+
+def test_render_furnace_and_determinism():
+    """White-furnace style check: inside a closed emissive box every path returns Le at its first hit."""
+    b = scenes._Builder("furnace")
+    m = b.material(scenes.Material("Light", _abi.MAT_DIFFUSE_LIGHT, emission=(0.5, 0.25, 2.0)))
+    v, uv = scenes.box((-1, -1, -1), (1, 1, 1))
+    b.mesh("box", m, v, uv)
+    sc = b.build(scenes.Camera(8, 8, 60.0, (0, 0, 0), (0, 0, -1)))
+    o = oracle.Oracle(sc)
+    img, cnt = o.render(spp=3, max_depth=5)
+    assert np.allclose(img, [0.5, 0.25, 2.0], rtol=1e-15)
+    assert cnt["rays_closest"] == 8 * 8 * 3 and cnt["rays_shadow"] == 0
+
+
+def test_render_background_and_depth_zero():
+    sc = one_triangle()
+    o = oracle.Oracle(sc)
+    img, _ = o.render(spp=2, max_depth=0, background=(0.1, 0.2, 0.3), sample_lights=False)
+    # pixels that miss the triangle see the background; hit pixels: depth 0 => scatter recursion returns 0
+    miss = np.isclose(img, [0.1, 0.2, 0.3]).all(-1)
+    assert miss.any() and (~miss).any()
+    assert np.allclose(img[~miss], 0.0)
+
+
+def test_peek_reuse_is_identical_and_threads_do_not_matter():
+    sc = scenes.mixed_materials(24, 24)
+    o = oracle.Oracle(sc)
+    a, ca = o.render(spp=4, max_depth=6, reuse_peek=True, nthreads=1)
+    b, cb = o.render(spp=4, max_depth=6, reuse_peek=False, nthreads=3)
+    assert np.array_equal(a, b)
+    assert ca["rays_closest"] == cb["rays_closest"] and cb["hit_calls"] > ca["hit_calls"]
+
+
+@pytest.mark.parametrize("name", ["tiny_cornell", "mixed"])
+def test_golden_fixture(name):
+    """Regression fixtures generated by tests/golden/make_golden.py from this oracle (self-pinned)."""
+    path = os.path.join(GOLD, f"{name}.npz")
+    g = np.load(path)
+    meta = json.loads(str(g["meta"]))
+    sc = scenes.tiny_scene() if name == "tiny_cornell" else scenes.mixed_materials()
+    o = oracle.Oracle(sc)
+    img, _ = o.render(spp=meta["spp"], max_depth=meta["max_depth"], seed=meta["seed"])
+    assert np.allclose(img, g["image"], rtol=1e-12, atol=1e-14)
+    h = o.trace_closest(g["rays"].view(_abi.RAY_DTYPE).reshape(-1))
+    assert np.array_equal(h["prim"], g["hit_prim"])
+    assert np.allclose(h["t"], g["hit_t"], rtol=1e-13)
+    assert np.array_equal(o.light_order(), g["light_order"])
