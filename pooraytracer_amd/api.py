@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _abi
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libprt_hip.so")
+_LIB_PATH = os.environ.get("PRT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libprt_hip.so")
 _lib = None
 
 
@@ -32,6 +32,14 @@ def load():
         return _lib
     if not os.path.exists(_LIB_PATH):
         raise PrtError(-100, f"{_LIB_PATH} not built; run `python -m pooraytracer_amd.build` (needs hipcc)")
+    # PyTorch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1 (same SONAMEs as /opt/rocm).
+    # Two HIP runtimes cannot coexist in one process, and torch fails to initialise on the system
+    # one, so when torch is importable it is imported first and this library binds to its runtime.
+    if not os.environ.get("PRT_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(_LIB_PATH)
     vp, sz, i32, u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
     L.prt_abi_version.restype = C.c_int

@@ -21,15 +21,16 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra_flags=()):
+def build(force=False, verbose=False, extra_flags=(), out=None):
     """Compile every HIP/C++ source of the hot path into pooraytracer_amd/libprt_hip.so."""
-    if not force and not stale():
+    if out is None and not force and not stale():
         return LIB
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+    out = out or LIB
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", out] + [os.path.join(CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

@@ -112,7 +112,13 @@ PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, double tmin, doubl
 template <bool COUNT>
 PRT_DEV void trace(const DScene& S, d3 o, d3 d, double tmin, double tmax, double early_t, HitInfo& hit,
                    uint32_t* stk, WorkCount& wc) {
-    const double idx = 1.0 / d.x, idy = 1.0 / d.y, idz = 1.0 / d.z;
+    // Slab test as t = fma(b, 1/d, -o/d).  A zero direction component would give inf - inf = NaN for
+    // one plane only and poison the min/max, so for the (conservative) box test it is replaced by a
+    // denormal-safe tiny value: planes of that axis then map to -/+1e300-scale t and never cull wrongly.
+    const double sx = fabs(d.x) < 1e-300 ? copysign(1e-300, d.x) : d.x;
+    const double sy = fabs(d.y) < 1e-300 ? copysign(1e-300, d.y) : d.y;
+    const double sz = fabs(d.z) < 1e-300 ? copysign(1e-300, d.z) : d.z;
+    const double idx = 1.0 / sx, idy = 1.0 / sy, idz = 1.0 / sz;
     const double oix = -o.x * idx, oiy = -o.y * idy, oiz = -o.z * idz;
     hit.t = tmax;
     hit.tri = -1;

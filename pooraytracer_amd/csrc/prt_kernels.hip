@@ -11,9 +11,10 @@
 //     (pixel, sample chunk) and pulls the next one from a global atomic counter when it finishes, so
 //     short paths (light / background pixels) never idle a wave for long — lane-level regeneration
 //     instead of a per-bounce compaction pass;
-//   * one loop iteration = one path vertex: all lanes trace their continuation ray together, shade,
-//     then the lanes that sample lights trace their shadow ray together (closest-hit semantics with a
-//     certain-occluder early-out), then Russian roulette + Scatter produce the next ray;
+//   * one loop iteration = ONE traversal per lane — a continuation ray or an NEE shadow ray, whichever
+//     that lane's path needs next — so the whole wave is always inside the same traversal code
+//     (single call site: half the registers of a trace/shade/trace/shade loop) and only the short
+//     shading tails diverge; shadow rays use closest-hit semantics with a certain-occluder early-out;
 //   * traversal stack in LDS, lane-strided (conflict-free), PRT_STACK_DEPTH entries per lane;
 //   * results are deterministic: per-sample keyed RNG, per-item partial sums combined in a fixed
 //     order by K5 (no float atomics on the framebuffer).
@@ -21,6 +22,11 @@
 
 #include "../../include/prt.h"
 #include "prt_device.h"
+
+// minimum resident waves per SIMD the register allocator must leave room for in K3
+#ifndef PRT_RENDER_WAVES
+#define PRT_RENDER_WAVES 2
+#endif
 
 namespace {
 
@@ -82,10 +88,34 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_trace_closest(DScene S, const Prt
 }
 
 // ------------------------------------------------------------------------------------------- K3
-enum : int { ST_FETCH = 0, ST_NEW_SAMPLE = 1, ST_TRACE = 2, ST_DONE = 3 };
+enum : int { ST_FETCH = 0, ST_NEW_SAMPLE = 1, ST_CLOSEST = 2, ST_SHADOW = 3, ST_DONE = 4 };
+
+// Shading context of a hit, rebuilt from (incoming ray, HitInfo): HitRecord of Triangle::Hit
+// (Triangle.cpp:76-80,111) — position = ray(t), face-forwarded normal, tangent, uv.
+struct ShadeCtx {
+    d3 pos;
+    Frame f;
+    d2 uv;
+    int32_t material;
+};
+PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 ro, d3 rd, const HitInfo& h) {
+    ShadeCtx c;
+    const DTriShade* sh = S.shade + h.tri;
+    const DTri* T = S.tris + h.tri;
+    const d3 gn = mk3(T->n[0], T->n[1], T->n[2]);
+    const bool front = dot(rd, gn) < 0.;
+    c.f.n = front ? gn : -gn;
+    c.f.t = ld3(sh->tangent);
+    c.pos = ro + rd * h.t;
+    const double w0 = 1. - h.alpha - h.beta;
+    c.uv.x = w0 * sh->uv0[0] + h.alpha * sh->uv1[0] + h.beta * sh->uv2[0];
+    c.uv.y = w0 * sh->uv0[1] + h.alpha * sh->uv1[1] + h.beta * sh->uv2[1];
+    c.material = sh->material;
+    return c;
+}
 
 template <bool COUNT>
-__global__ __launch_bounds__(PRT_BLOCK) void k_render(DScene S, DCamera C, DRenderParams P, double* __restrict__ partial,
+__global__ __launch_bounds__(PRT_BLOCK, PRT_RENDER_WAVES) void k_render(DScene S, DCamera C, DRenderParams P, double* __restrict__ partial,
                                                       DCounters* ctr) {
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -101,11 +131,14 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_render(DScene S, DCamera C, DRend
     d3 acc = mk3(0, 0, 0);  // sum over this item's samples of colour * (1/spp)
     d3 L = mk3(0, 0, 0);    // radiance of the current sample
     d3 beta = mk3(1, 1, 1); // path throughput
-    d3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1);
+    d3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1); // the ray whose closest hit is being shaded
+    HitInfo sh;                               // its hit (valid in ST_SHADOW)
+    sh.t = 0; sh.alpha = 0; sh.beta = 0; sh.tri = -1;
+    d3 lpos = mk3(0, 0, 0);                   // sampled light point (valid in ST_SHADOW)
+    int32_t ltri = 0;
     Rng rng;
     rng.s = 0;
     const double inv_spp = 1.0 / P.spp; // pixelSamplesScale, Camera.cpp:83
-    const d3 bg = ld3(P.background);
 
     for (;;) {
         if (state == ST_FETCH) {
@@ -141,85 +174,107 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_render(DScene S, DCamera C, DRend
             first = true;
             prev_skip = false;
             n_samples++;
-            state = ST_TRACE;
+            state = ST_CLOSEST;
         }
 
-        if (state == ST_TRACE) {
-            bool end_sample = false;
-            HitInfo h;
-            n_closest++;
-            trace<COUNT>(S, ro, rd, 0.0001, PRT_INF, -PRT_INF, h, stk, wc); // Camera.cpp:125
-            if (h.tri < 0) {
-                // miss: background for the camera ray (Camera.cpp:127); with bSampleLights a bounce miss adds 0 (:187)
-                if (first || !P.sample_lights) L = L + beta * bg;
-                end_sample = true;
+        if (state == ST_CLOSEST || state == ST_SHADOW) {
+            // ---- one traversal per lane per iteration: continuation ray or NEE shadow ray
+            d3 to = ro, td = rd;
+            double tmin = 0.0001, tmax = PRT_INF, early = -PRT_INF, dist = 0.0; // Camera.cpp:125
+            if (state == ST_SHADOW) {
+                // Ray(ps, normalize(pl-ps)), Interval(0.001, DBL_MAX) (Camera.cpp:143-150).  Any hit nearer
+                // than dist-1e-3 (minus a safety margin) proves occlusion, so traversal may stop there.
+                to = ro + rd * sh.t;
+                const d3 toL = lpos - to;
+                td = normalize(toL);
+                dist = length(toL);
+                tmin = 0.001;
+                tmax = 1.7976931348623157e308;
+                early = dist - 0.001 - 1e-6;
+                n_shadow++;
             } else {
-                const DTriShade sh = S.shade[h.tri];
-                const DMaterial& m = S.materials[sh.material];
-                if (m.has_emission) {
-                    // Camera.cpp:129-132; via a bounce only after SkipLightSampling materials (:191-195)
-                    if (first || !P.sample_lights || prev_skip) L = L + beta * ld3(m.emission);
+                n_closest++;
+            }
+            HitInfo h;
+            trace<COUNT>(S, to, td, tmin, tmax, early, h, stk, wc);
+
+            bool end_sample = false, do_scatter = false;
+            if (state == ST_CLOSEST) {
+                if (h.tri < 0) {
+                    // miss: background for the camera ray (Camera.cpp:127); with bSampleLights a bounce miss adds 0 (:187)
+                    if (first || !P.sample_lights) L = L + beta * ld3(P.background);
                     end_sample = true;
                 } else {
-                    const DTri* T = S.tris + h.tri;
-                    const d3 gn = mk3(T->n[0], T->n[1], T->n[2]);
-                    const bool front = dot(rd, gn) < 0.;
-                    Frame f;
-                    f.n = front ? gn : -gn;
-                    f.t = ld3(sh.tangent);
-                    const d3 pos = ro + rd * h.t; // record.position = ray(t)
-                    d2 uv;                        // Triangle.cpp:111
-                    {
-                        const double w0 = 1. - h.alpha - h.beta;
-                        uv.x = w0 * sh.uv0[0] + h.alpha * sh.uv1[0] + h.beta * sh.uv2[0];
-                        uv.y = w0 * sh.uv0[1] + h.alpha * sh.uv1[1] + h.beta * sh.uv2[1];
-                    }
-                    // ---- next-event estimation, Camera.cpp:137-173
-                    if (P.sample_lights && S.n_lights > 0 && !m.skip_light_sampling) {
-                        const LightPick lp = sample_lights(S, pos, rng);
-                        const d3 toL = lp.pos - pos;
-                        const d3 ldir = normalize(toL);
-                        const double dist = length(toL);
-                        if (dot(f.n, ldir) > 0.0 && lp.front) {
-                            // visibility = closest hit along the shadow ray no nearer than dist-1e-3 (:150-155)
-                            HitInfo sh_hit;
-                            n_shadow++;
-                            trace<COUNT>(S, pos, ldir, 0.001, 1.7976931348623157e308, dist - 0.001 - 1e-6, sh_hit, stk, wc);
-                            bool visible = true; // an escaping shadow ray counts as unoccluded
-                            if (sh_hit.tri >= 0) {
-                                const d3 pn = pos + ldir * sh_hit.t;
-                                visible = (dist - length(pos - pn)) < 0.001;
-                            }
-                            if (visible) {
-                                const DLightTri* lt = S.light_tris + lp.tri;
-                                const d3 emission = ld3(S.materials[lt->material].emission);
-                                const d3 wo = world_to_local(-rd, f);
-                                const d3 lwi = world_to_local(ldir, f);
-                                const d3 lln = world_to_local(lp.n, f);
-                                const d3 fr = mat_eval(S, m, lwi, wo, uv, rng);
-                                const double cosT = lwi.z;
-                                const double cosTB = dot(lln, -lwi);
-                                const d3 direct = emission * fr * cosT * cosTB / (dist * dist) / lp.pdf;
-                                L = L + beta * direct;
+                    const DMaterial& m = S.materials[S.shade[h.tri].material];
+                    if (m.has_emission) {
+                        // Camera.cpp:129-132; via a bounce only after SkipLightSampling materials (:191-195)
+                        if (first || !P.sample_lights || prev_skip) L = L + beta * ld3(m.emission);
+                        end_sample = true;
+                    } else {
+                        sh = h;
+                        do_scatter = true;
+                        if (P.sample_lights && S.n_lights > 0 && !m.skip_light_sampling) {
+                            // next-event estimation, Camera.cpp:137-155: pick the light point now (4 draws)
+                            const ShadeCtx c = make_ctx(S, ro, rd, sh);
+                            const LightPick lp = sample_lights(S, c.pos, rng);
+                            const d3 ldir = normalize(lp.pos - c.pos);
+                            if (dot(c.f.n, ldir) > 0.0 && lp.front) {
+                                lpos = lp.pos;
+                                ltri = lp.tri;
+                                state = ST_SHADOW; // trace the shadow ray next iteration, then scatter
+                                do_scatter = false;
                             }
                         }
                     }
-                    // ---- Russian roulette + Scatter, Camera.cpp:176-202
-                    end_sample = true;
-                    if (rng.next() < P.rr) {
-                        d3 att, wi;
-                        if (mat_scatter(S, m, rd, f, uv, rng, att, wi)) {
-                            depth--; // RayColor(scattered, depth-1): returns 0 when depth-1 < 0
-                            if (depth >= 0) {
-                                beta = beta * att / P.rr;
-                                // a zero throughput (Phong bad sample) contributes exactly 0 from here on
-                                if (!(beta.x == 0. && beta.y == 0. && beta.z == 0.)) {
-                                    ro = pos;
-                                    rd = wi;
-                                    prev_skip = m.skip_light_sampling != 0;
-                                    first = false;
-                                    end_sample = false;
-                                }
+                }
+            } else {
+                // ---- shadow ray returned: visibility = closest hit no nearer than dist - 1e-3 (Camera.cpp:152-155)
+                const ShadeCtx c = make_ctx(S, ro, rd, sh);
+                bool visible = true; // an escaping shadow ray counts as unoccluded
+                if (h.tri >= 0) {
+                    const d3 pn = to + td * h.t;
+                    visible = (dist - length(to - pn)) < 0.001;
+                }
+                if (visible) {
+                    const DMaterial& m = S.materials[c.material];
+                    const DLightTri* lt = S.light_tris + ltri;
+                    const d3 ln0 = ld3(lt->n);
+                    const d3 ln = dot(lpos - c.pos, ln0) < 0. ? ln0 : -ln0; // SetFaceNormal, Triangle.cpp:89-90
+                    double pdf = 1.0 / lt->area;                             // Triangle.cpp:92, BVH.cpp:91,66
+                    pdf *= lt->area;
+                    pdf /= S.light_area;
+                    const d3 emission = ld3(S.materials[lt->material].emission);
+                    const d3 wo = world_to_local(-rd, c.f);
+                    const d3 lwi = world_to_local(td, c.f);
+                    const d3 lln = world_to_local(ln, c.f);
+                    const d3 fr = mat_eval(S, m, lwi, wo, c.uv, rng);
+                    const double cosT = lwi.z;
+                    const double cosTB = dot(lln, -lwi);
+                    const d3 direct = emission * fr * cosT * cosTB / (dist * dist) / pdf; // Camera.cpp:172
+                    L = L + beta * direct;
+                }
+                state = ST_CLOSEST;
+                do_scatter = true;
+            }
+
+            if (do_scatter) {
+                // ---- Russian roulette + Scatter, Camera.cpp:176-202
+                end_sample = true;
+                if (rng.next() < P.rr) {
+                    const ShadeCtx c = make_ctx(S, ro, rd, sh);
+                    const DMaterial& m = S.materials[c.material];
+                    d3 att, wi;
+                    if (mat_scatter(S, m, rd, c.f, c.uv, rng, att, wi)) {
+                        depth--; // RayColor(scattered, depth-1): returns 0 when depth-1 < 0
+                        if (depth >= 0) {
+                            beta = beta * att / P.rr;
+                            // a zero throughput (Phong bad sample) contributes exactly 0 from here on
+                            if (!(beta.x == 0. && beta.y == 0. && beta.z == 0.)) {
+                                ro = c.pos;
+                                rd = wi;
+                                prev_skip = m.skip_light_sampling != 0;
+                                first = false;
+                                end_sample = false;
                             }
                         }
                     }
