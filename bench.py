@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X path-tracing hot path.
+
+Metric (BASELINE.json): Mrays/s (primary + secondary) and wall-clock s/frame at fixed spp.
+Workload at N=1 (BASELINE.json configs[1]): synthetic "cornell-box" stand-in (scenes.cornell_box,
+20,492 triangles — the reference's asset is not available), 1024x1024, spp=500, depth=20, RR 0.8,
+bSampleLights, seed 1, fp64 arithmetic (the reference's).  One "step" = one full frame
+(Camera::Render): K3 persistent path-tracing kernel + K5 finalize, inputs (scene, BVH) resident in HBM.
+
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL).  The SAME frame is cut into 32x32
+tiles dealt round-robin over ranks (strong scaling: total work fixed); every rank renders its tiles
+into a zero-initialised full-size fp32 framebuffer and one RCCL reduce(sum) to rank 0 assembles the
+image (disjoint tiles => x + 0 + ... + 0, bit-identical to the 1-GPU image).  The reduce is inside
+the timed region.
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     dominant kernel k_render: algorithmic bytes per launch / mean launch duration measured
+               live with HIP events on the launch stream (library-side hipEventRecord around K3).
+  cpu_baseline the CPU oracle (port of the reference algorithm, oracle/pt_oracle.cpp) timed on this
+               box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E nominal (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+
+WORKLOADS = {
+    # name: (scene factory name, kwargs, spp, depth)
+    "cornell-box": ("cornell_box", {}, 500, 20),
+    "veach-mis": ("veach_mis", {}, 3000, 100),
+    "bathroom2": ("bathroom", {}, 100, 50),
+}
+
+
+def bytes_per_ray(nodes_per_ray, tris_per_ray):
+    """ray in (64 B fp64 o,tmin,d,tmax) + hit out (32 B) + 64 B per BVH node record
+    fetched + 128 B per fp64 triangle record tested (counters from the counting instantiation)."""
+    return 64.0 + 32.0 + 64.0 * nodes_per_ray + 128.0 * tris_per_ray
+
+
+def cpu_baseline(scene_data, spp, depth, seed, target_s=12.0):
+    """Time the CPU oracle (kind "port") on a bounded sample: centre rows of the same image at the
+    same spp/depth, all host threads as independent row workers with keyed per-sample RNG."""
+    import oracle  # test infrastructure used here only as the reported CPU baseline
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    orc = oracle.Oracle(scene_data)
+    cam = scene_data.camera
+    mid = cam.height // 2
+    # calibration: a few rows at low spp
+    t = time.time()
+    _, c = orc.render(spp=8, max_depth=depth, seed=seed, rows=(mid, mid + threads), nthreads=threads)
+    dt = max(time.time() - t, 1e-3)
+    paths_per_s = c["samples"] / dt
+    rows = int(max(threads, min(cam.height, (paths_per_s * target_s) / (cam.width * spp))))
+    rows = max(threads, (rows // threads) * threads)
+    y0 = max(0, mid - rows // 2)
+    t = time.time()
+    _, c = orc.render(spp=spp, max_depth=depth, seed=seed, rows=(y0, y0 + rows), nthreads=threads)
+    dt = time.time() - t
+    rays = c["rays_closest"] + c["rays_shadow"]
+    return {
+        "value": round(rays / dt / 1e6, 3),
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"rows {y0}..{y0 + rows} of the {cam.width}x{cam.height} frame at spp={spp} depth={depth} "
+                  f"({c['samples']} camera samples, {rays} rays, {dt:.2f} s, {threads} row-worker threads)",
+        "mpaths_per_s": round(c["samples"] / dt / 1e6, 4),
+        "seconds": round(dt, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell-box", choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override spp (0 = the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    nranks = world
+
+    import torch
+    import torch.distributed as dist
+    from pooraytracer_amd import api, build, scenes
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if rank == 0:
+        build.build()  # no-op when libprt_hip.so is fresh
+    torch.cuda.set_device(local_rank)
+    if nranks > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=nranks,
+                                device_id=torch.device("cuda", local_rank))
+        dist.barrier()
+
+    fn, kw, spp, depth = WORKLOADS[args.workload]
+    if args.spp > 0:
+        spp = args.spp
+    seed = 1
+    data = getattr(scenes, fn)(**kw)
+    cam = data.camera
+    sc = api.Scene(data).upload(local_rank)
+    fb = torch.zeros((cam.height, cam.width, 3), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    render_kw = dict(spp=spp, max_depth=depth, seed=seed, rank=rank, nranks=nranks, tile_size=32)
+
+    def step():
+        sc.render_device(None, fb.data_ptr(), stream=stream, **render_kw)
+        if nranks > 1:
+            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+
+    def fence():
+        if nranks > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = []
+    rays = 0
+    samples = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        c = sc.counters()  # waits for this step's K3 (HIP events on the launch stream) and reads ray counters
+        kernel_ms.append(c["kernel_ms"])
+        rays += c["rays_closest"] + c["rays_shadow"]
+        samples += c["samples"]
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if nranks > 1:
+        t = torch.tensor([elapsed, float(rays), float(samples)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        rays, samples = int(t[1]), int(t[2])
+
+    if rank == 0:
+        # counting instantiation (outside the timed region): mean node fetches / triangle tests per ray
+        sc.render_device(None, fb.data_ptr(), count_work=True, stream=stream,
+                         **dict(render_kw, spp=min(spp, 8), rank=0, nranks=1))
+        torch.cuda.synchronize()
+        cc = sc.counters()
+        cr = max(1, cc["rays_closest"] + cc["rays_shadow"])
+        npr, tpr = cc["node_fetches"] / cr, cc["tri_tests"] / cr
+        bpr = bytes_per_ray(npr, tpr)
+        rays_per_launch = rays / args.steps / nranks  # this rank's launch (tiles are balanced round-robin)
+        mean_ms = sum(kernel_ms) / len(kernel_ms)
+        fb_bytes = 24.0 * cam.width * cam.height / nranks  # fp64 per-item partial sums written by K3
+        achieved = (bpr * rays_per_launch + fb_bytes) / (mean_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/s (primary+secondary) at fixed spp; s/frame in ms_per_step",
+            "value": round(rays / elapsed / 1e6, 2),
+            "unit": "Mrays/s",
+            "n_gpus": nranks,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload} (synthetic stand-in, {data.n_tris} tris) {cam.width}x{cam.height} "
+                            f"spp={spp} depth={depth} rr=0.8 bSampleLights seed={seed}",
+                "parallelism": f"tiles32 round-robin over {nranks} GPU(s)" + (" + RCCL reduce(sum) of fp32 framebuffer" if nranks > 1 else ""),
+                "mpaths_per_s": round(samples / elapsed / 1e6, 3),
+                "rays_per_frame": int(rays / args.steps),
+                "s_per_frame": round(elapsed / args.steps, 4),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                "traffic": None,
+                "kernel": "k_render",
+                "kernel_ms": round(mean_ms, 3),
+                "bytes_per_ray": round(bpr, 1),
+                "nodes_per_ray": round(npr, 2),
+                "tris_per_ray": round(tpr, 2),
+            },
+        }
+        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(prof):  # PMC-measured HBM bytes per launch of this workload (separate rocprofv3 --pmc passes)
+            try:
+                tr = json.load(open(prof)).get(args.workload)
+                if tr and tr.get("spp") == spp and nranks == 1:
+                    out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            except Exception:
+                pass
+        if nranks == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(data, spp, depth, seed)
+            out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 1)
+        print(json.dumps(out), flush=True)
+    if nranks > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

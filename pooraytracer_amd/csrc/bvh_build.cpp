@@ -201,7 +201,7 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
     }
     Builder b(out.nodes);
     b.prims.resize(n);
-    // inflation: covers the rounding of fma(b, 1/d, -o/d) against (b-o)/d for |o| up to ~1e6 scene units
+    // small absolute inflation on top of the outward rounding (the kernel adds its own per-ray pad)
     double scale = 1.0;
     for (const HostTri& t : tris)
         for (int a = 0; a < 3; ++a) scale = std::max(scale, std::max(std::fabs(t.lo[a]), std::fabs(t.hi[a])));
@@ -229,6 +229,10 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
         b.build(0, (uint32_t)n, kMaxLevels, 0, root, true);
     }
     out.depth = b.max_depth;
+    float cs = 0.f;
+    for (const PrimRef& pr : b.prims)
+        for (int a = 0; a < 3; ++a) cs = std::max(cs, std::max(std::fabs(pr.lo[a]), std::fabs(pr.hi[a])));
+    out.coord_scale = std::nextafter(cs, std::numeric_limits<float>::infinity());
     out.order.resize(n);
     for (size_t i = 0; i < n; ++i) out.order[i] = b.prims[i].idx;
     return true;

@@ -243,6 +243,7 @@ int prt_scene_upload(PrtScene* s, int device) {
     d.light_area = s->lights.area;
     d.n_nodes = (uint32_t)s->bvh.nodes.size();
     d.n_tris = (uint32_t)n;
+    d.coord_scale = s->bvh.coord_scale;
     PRT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_ctr), sizeof(DCounters)));
     PRT_HIP(hipMemset(s->d_ctr, 0, sizeof(DCounters)));
     PRT_HIP(hipEventCreate(&s->ev0));

@@ -104,22 +104,52 @@ PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, double tmin, doubl
     return true;
 }
 
+// Conservative double -> float conversions (round-to-nearest error <= 2^-24 relative, widened by 2^-22).
+PRT_DEV float f32_up(double x) {
+    const float f = (float)x;
+    return f + fabsf(f) * 2.4e-7f;
+}
+PRT_DEV float f32_down(double x) {
+    const float f = (float)x;
+    return f - fabsf(f) * 2.4e-7f;
+}
+
+// Per-ray constants of the fp32 slab test  t(b) = fma(b, id, c):  id ~ 1/d, c = -o*id, with the
+// rounding of o, 1/d, the product and the fma (<= 6 * 2^-24 * (|o|+B) * |id| in t, B = largest box
+// coordinate) covered by pad = 2^-21 * (|o|+B) * |id|, subtracted on the entry plane and added on the
+// exit plane.  |id| is clamped to 1e28 so a zero direction component never produces inf - inf.
+struct SlabAxis {
+    float id, c_lo, c_hi;
+};
+PRT_DEV SlabAxis slab_axis(double o, double d, float B) {
+    SlabAxis a;
+    const float df = (float)d;
+    float id = 1.0f / df;
+    if (!(fabsf(id) <= 1e28f)) id = copysignf(1e28f, df);
+    const float of = (float)o;
+    const float c = -of * id;
+    const float pad = fabsf(id) * (fabsf(of) + B) * 4.76837158e-7f;
+    a.id = id;
+    a.c_lo = id >= 0.f ? c - pad : c + pad; // the lo plane is the entry plane when id >= 0
+    a.c_hi = id >= 0.f ? c + pad : c - pad;
+    return a;
+}
+
 // Closest hit in [tmin, tmax] (replaces world.Hit: HittableList.h:26-39 -> BVH.cpp:51-61 -> AABB.cpp:38-64).
 // The result is tree-independent (closest accepted triangle; on exactly equal t the later-tested one
-// wins, as in the reference).  `early_t`: traversal stops as soon as a hit with t < early_t is
-// accepted (shadow rays: anything that close is an occluder for certain); pass -inf for closest-hit.
-// `stk` points at this lane's column of the wave's LDS stack (stride 64 words).
+// wins, as in the reference).  Box tests are fp32 and strictly conservative (they can only fail to
+// cull); every accept/reject of a hit is the fp64 triangle test.  `early_t`: traversal stops as soon
+// as a hit with t < early_t is accepted (shadow rays: anything that close is an occluder for
+// certain); pass -inf for closest-hit.  `stk` points at this lane's column of the wave's LDS stack
+// (stride 64 words).
 template <bool COUNT>
 PRT_DEV void trace(const DScene& S, d3 o, d3 d, double tmin, double tmax, double early_t, HitInfo& hit,
                    uint32_t* stk, WorkCount& wc) {
-    // Slab test as t = fma(b, 1/d, -o/d).  A zero direction component would give inf - inf = NaN for
-    // one plane only and poison the min/max, so for the (conservative) box test it is replaced by a
-    // denormal-safe tiny value: planes of that axis then map to -/+1e300-scale t and never cull wrongly.
-    const double sx = fabs(d.x) < 1e-300 ? copysign(1e-300, d.x) : d.x;
-    const double sy = fabs(d.y) < 1e-300 ? copysign(1e-300, d.y) : d.y;
-    const double sz = fabs(d.z) < 1e-300 ? copysign(1e-300, d.z) : d.z;
-    const double idx = 1.0 / sx, idy = 1.0 / sy, idz = 1.0 / sz;
-    const double oix = -o.x * idx, oiy = -o.y * idy, oiz = -o.z * idz;
+    const SlabAxis ax = slab_axis(o.x, d.x, S.coord_scale);
+    const SlabAxis ay = slab_axis(o.y, d.y, S.coord_scale);
+    const SlabAxis az = slab_axis(o.z, d.z, S.coord_scale);
+    const float tminf = f32_down(tmin);
+    float tbestf = f32_up(tmax);
     hit.t = tmax;
     hit.tri = -1;
     hit.alpha = 0.0;
@@ -129,35 +159,35 @@ PRT_DEV void trace(const DScene& S, d3 o, d3 d, double tmin, double tmax, double
     for (;;) {
         if (cur >= 0) {
             const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-            float4 a = np[0], b = np[1], c = np[2];
-            int2 refs = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(S.nodes + cur) + 48);
+            const float4 a = np[0], b = np[1], c = np[2];
+            const int2 refs = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(S.nodes + cur) + 48);
             if (COUNT) wc.nodes++;
             // child 0: a = (lo.x,hi.x,lo.y,hi.y), b.xy = (lo.z,hi.z)
-            double t0 = fma((double)a.x, idx, oix), t1 = fma((double)a.y, idx, oix);
-            double tn0 = fmin(t0, t1), tf0 = fmax(t0, t1);
-            t0 = fma((double)a.z, idy, oiy);
-            t1 = fma((double)a.w, idy, oiy);
-            tn0 = fmax(tn0, fmin(t0, t1));
-            tf0 = fmin(tf0, fmax(t0, t1));
-            t0 = fma((double)b.x, idz, oiz);
-            t1 = fma((double)b.y, idz, oiz);
-            tn0 = fmax(fmax(tn0, fmin(t0, t1)), tmin);
-            tf0 = fmin(fmin(tf0, fmax(t0, t1)), hit.t);
+            float l = fmaf(a.x, ax.id, ax.c_lo), h = fmaf(a.y, ax.id, ax.c_hi);
+            float n0 = fminf(l, h), f0 = fmaxf(l, h);
+            l = fmaf(a.z, ay.id, ay.c_lo);
+            h = fmaf(a.w, ay.id, ay.c_hi);
+            n0 = fmaxf(n0, fminf(l, h));
+            f0 = fminf(f0, fmaxf(l, h));
+            l = fmaf(b.x, az.id, az.c_lo);
+            h = fmaf(b.y, az.id, az.c_hi);
+            n0 = fmaxf(fmaxf(n0, fminf(l, h)), tminf);
+            f0 = fminf(fminf(f0, fmaxf(l, h)), tbestf);
             // child 1: b.zw = (lo.x,hi.x), c = (lo.y,hi.y,lo.z,hi.z)
-            t0 = fma((double)b.z, idx, oix);
-            t1 = fma((double)b.w, idx, oix);
-            double tn1 = fmin(t0, t1), tf1 = fmax(t0, t1);
-            t0 = fma((double)c.x, idy, oiy);
-            t1 = fma((double)c.y, idy, oiy);
-            tn1 = fmax(tn1, fmin(t0, t1));
-            tf1 = fmin(tf1, fmax(t0, t1));
-            t0 = fma((double)c.z, idz, oiz);
-            t1 = fma((double)c.w, idz, oiz);
-            tn1 = fmax(fmax(tn1, fmin(t0, t1)), tmin);
-            tf1 = fmin(fmin(tf1, fmax(t0, t1)), hit.t);
-            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+            l = fmaf(b.z, ax.id, ax.c_lo);
+            h = fmaf(b.w, ax.id, ax.c_hi);
+            float n1 = fminf(l, h), f1 = fmaxf(l, h);
+            l = fmaf(c.x, ay.id, ay.c_lo);
+            h = fmaf(c.y, ay.id, ay.c_hi);
+            n1 = fmaxf(n1, fminf(l, h));
+            f1 = fminf(f1, fmaxf(l, h));
+            l = fmaf(c.z, az.id, az.c_lo);
+            h = fmaf(c.w, az.id, az.c_hi);
+            n1 = fmaxf(fmaxf(n1, fminf(l, h)), tminf);
+            f1 = fminf(fminf(f1, fmaxf(l, h)), tbestf);
+            const bool h0 = n0 <= f0, h1 = n1 <= f1;
             if (h0 && h1) {
-                const bool swap = tn1 < tn0;
+                const bool swap = n1 < n0;
                 const int32_t nearRef = swap ? refs.y : refs.x;
                 const int32_t farRef = swap ? refs.x : refs.y;
                 stk[sp * 64] = (uint32_t)farRef;
@@ -184,6 +214,7 @@ PRT_DEV void trace(const DScene& S, d3 o, d3 d, double tmin, double tmax, double
                     hit.alpha = al;
                     hit.beta = be;
                     hit.tri = (int32_t)(first + i);
+                    tbestf = f32_up(t);
                     if (t < early_t) stop = true;
                 }
             }

@@ -25,6 +25,7 @@ struct BuiltBVH {
     std::vector<DNode> nodes;    // nodes[0] is the root
     std::vector<uint32_t> order; // BVH leaf order -> index into the HostTri array
     uint32_t depth = 0;
+    float coord_scale = 1.0f;    // >= |every box coordinate|
 };
 
 struct LightTree {

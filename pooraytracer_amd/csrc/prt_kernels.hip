@@ -25,7 +25,7 @@
 
 // minimum resident waves per SIMD the register allocator must leave room for in K3
 #ifndef PRT_RENDER_WAVES
-#define PRT_RENDER_WAVES 2
+#define PRT_RENDER_WAVES 4
 #endif
 
 namespace {

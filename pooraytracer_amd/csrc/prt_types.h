@@ -12,7 +12,9 @@
 #include <stdint.h>
 
 #define PRT_STACK_DEPTH 32   // LDS traversal stack entries per lane; builder bounds tree depth to it
+#ifndef PRT_LEAF_MAX
 #define PRT_LEAF_MAX 4       // triangles per BVH leaf (leaf ref stores count-1 in 3 bits)
+#endif
 #define PRT_BLOCK 256        // threads per workgroup (4 wave64)
 
 struct alignas(64) DNode {
@@ -87,6 +89,8 @@ struct DScene {
     int32_t n_lights;
     double light_area;  // GetArea() of the top-level lights BVHNode
     uint32_t n_nodes, n_tris;
+    float coord_scale;  // largest |coordinate| of any BVH box (fp32, rounded up): bounds the slab-test rounding
+    float pad_;
 };
 
 // camera state after Camera::Initialize (Camera.cpp:75-106), computed on the host
