@@ -12,6 +12,12 @@
 #include "prt_types.h"
 
 #define PRT_DEV __device__ __forceinline__
+#ifndef PRT_LEAF_BATCH
+#define PRT_LEAF_BATCH 32 // parked lanes that trigger a leaf round
+#endif
+#ifndef PRT_INNER_MIN
+#define PRT_INNER_MIN 12  // ... or at most this many lanes still at inner nodes
+#endif
 
 // ------------------------------------------------------------------ dvec3 subset (glm semantics)
 struct d3 {
@@ -135,95 +141,139 @@ PRT_DEV SlabAxis slab_axis(double o, double d, float B) {
     return a;
 }
 
-// Closest hit in [tmin, tmax] (replaces world.Hit: HittableList.h:26-39 -> BVH.cpp:51-61 -> AABB.cpp:38-64).
+// Closest hit in [tmin, tmax] (replaces world.Hit: HittableList.h:26-39 -> BVH.cpp:51-61 -> AABB.cpp:38-64)
+// as a resumable per-lane traversal: init() starts a ray, step() executes ONE node visit or ONE leaf,
+// `active` drops when the traversal is complete.  Keeping the traversal resumable lets a wave leave
+// the stepping loop as soon as enough of its lanes have finished (ballot/popcount), hand those lanes
+// their next ray, and come back — lanes never idle for the slowest ray of the wave.
+//
 // The result is tree-independent (closest accepted triangle; on exactly equal t the later-tested one
 // wins, as in the reference).  Box tests are fp32 and strictly conservative (they can only fail to
-// cull); every accept/reject of a hit is the fp64 triangle test.  `early_t`: traversal stops as soon
-// as a hit with t < early_t is accepted (shadow rays: anything that close is an occluder for
-// certain); pass -inf for closest-hit.  `stk` points at this lane's column of the wave's LDS stack
-// (stride 64 words).
-template <bool COUNT>
-PRT_DEV void trace(const DScene& S, d3 o, d3 d, double tmin, double tmax, double early_t, HitInfo& hit,
-                   uint32_t* stk, WorkCount& wc) {
-    const SlabAxis ax = slab_axis(o.x, d.x, S.coord_scale);
-    const SlabAxis ay = slab_axis(o.y, d.y, S.coord_scale);
-    const SlabAxis az = slab_axis(o.z, d.z, S.coord_scale);
-    const float tminf = f32_down(tmin);
-    float tbestf = f32_up(tmax);
-    hit.t = tmax;
-    hit.tri = -1;
-    hit.alpha = 0.0;
-    hit.beta = 0.0;
-    int sp = 0;
-    int32_t cur = 0;
-    for (;;) {
-        if (cur >= 0) {
-            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-            const float4 a = np[0], b = np[1], c = np[2];
-            const int2 refs = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(S.nodes + cur) + 48);
-            if (COUNT) wc.nodes++;
-            // child 0: a = (lo.x,hi.x,lo.y,hi.y), b.xy = (lo.z,hi.z)
-            float l = fmaf(a.x, ax.id, ax.c_lo), h = fmaf(a.y, ax.id, ax.c_hi);
-            float n0 = fminf(l, h), f0 = fmaxf(l, h);
-            l = fmaf(a.z, ay.id, ay.c_lo);
-            h = fmaf(a.w, ay.id, ay.c_hi);
-            n0 = fmaxf(n0, fminf(l, h));
-            f0 = fminf(f0, fmaxf(l, h));
-            l = fmaf(b.x, az.id, az.c_lo);
-            h = fmaf(b.y, az.id, az.c_hi);
-            n0 = fmaxf(fmaxf(n0, fminf(l, h)), tminf);
-            f0 = fminf(fminf(f0, fmaxf(l, h)), tbestf);
-            // child 1: b.zw = (lo.x,hi.x), c = (lo.y,hi.y,lo.z,hi.z)
-            l = fmaf(b.z, ax.id, ax.c_lo);
-            h = fmaf(b.w, ax.id, ax.c_hi);
-            float n1 = fminf(l, h), f1 = fmaxf(l, h);
-            l = fmaf(c.x, ay.id, ay.c_lo);
-            h = fmaf(c.y, ay.id, ay.c_hi);
-            n1 = fmaxf(n1, fminf(l, h));
-            f1 = fminf(f1, fmaxf(l, h));
-            l = fmaf(c.z, az.id, az.c_lo);
-            h = fmaf(c.w, az.id, az.c_hi);
-            n1 = fmaxf(fmaxf(n1, fminf(l, h)), tminf);
-            f1 = fminf(fminf(f1, fmaxf(l, h)), tbestf);
-            const bool h0 = n0 <= f0, h1 = n1 <= f1;
-            if (h0 && h1) {
-                const bool swap = n1 < n0;
-                const int32_t nearRef = swap ? refs.y : refs.x;
-                const int32_t farRef = swap ? refs.x : refs.y;
-                stk[sp * 64] = (uint32_t)farRef;
-                sp++;
-                cur = nearRef;
-            } else if (h0) {
-                cur = refs.x;
-            } else if (h1) {
-                cur = refs.y;
-            } else {
-                if (sp == 0) break;
-                sp--;
-                cur = (int32_t)stk[sp * 64];
-            }
+// cull); every accept/reject of a hit is the fp64 triangle test.  `early`: traversal stops as soon as
+// a hit with t < early is accepted (shadow rays: anything that close is an occluder for certain);
+// -inf for closest-hit.  The stack lives in LDS, lane-strided (`stk` = this lane's column, stride 64).
+struct Trav {
+    d3 o, d;
+    double tmin, early;
+    HitInfo hit;
+    SlabAxis ax, ay, az;
+    float tminf, tbestf;
+    int32_t cur;
+    int32_t sp;
+    bool active;
+
+    PRT_DEV void init(const DScene& S, d3 o_, d3 d_, double tmin_, double tmax_, double early_) {
+        o = o_;
+        d = d_;
+        tmin = tmin_;
+        early = early_;
+        ax = slab_axis(o.x, d.x, S.coord_scale);
+        ay = slab_axis(o.y, d.y, S.coord_scale);
+        az = slab_axis(o.z, d.z, S.coord_scale);
+        tminf = f32_down(tmin_);
+        tbestf = f32_up(tmax_);
+        hit.t = tmax_;
+        hit.tri = -1;
+        hit.alpha = 0.0;
+        hit.beta = 0.0;
+        sp = 0;
+        cur = 0;
+        active = S.n_tris != 0;
+    }
+
+    // One inner-node visit: fetch the 64-byte node, test both child boxes, descend / push / pop.
+    template <bool COUNT>
+    PRT_DEV void inner_step(const DScene& S, uint32_t* stk, WorkCount& wc) {
+        const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+        const float4 a = np[0], b = np[1], c = np[2];
+        const int2 refs = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(S.nodes + cur) + 48);
+        if (COUNT) wc.nodes++;
+        // child 0: a = (lo.x,hi.x,lo.y,hi.y), b.xy = (lo.z,hi.z)
+        float l = fmaf(a.x, ax.id, ax.c_lo), h = fmaf(a.y, ax.id, ax.c_hi);
+        float n0 = fminf(l, h), f0 = fmaxf(l, h);
+        l = fmaf(a.z, ay.id, ay.c_lo);
+        h = fmaf(a.w, ay.id, ay.c_hi);
+        n0 = fmaxf(n0, fminf(l, h));
+        f0 = fminf(f0, fmaxf(l, h));
+        l = fmaf(b.x, az.id, az.c_lo);
+        h = fmaf(b.y, az.id, az.c_hi);
+        n0 = fmaxf(fmaxf(n0, fminf(l, h)), tminf);
+        f0 = fminf(fminf(f0, fmaxf(l, h)), tbestf);
+        // child 1: b.zw = (lo.x,hi.x), c = (lo.y,hi.y,lo.z,hi.z)
+        l = fmaf(b.z, ax.id, ax.c_lo);
+        h = fmaf(b.w, ax.id, ax.c_hi);
+        float n1 = fminf(l, h), f1 = fmaxf(l, h);
+        l = fmaf(c.x, ay.id, ay.c_lo);
+        h = fmaf(c.y, ay.id, ay.c_hi);
+        n1 = fmaxf(n1, fminf(l, h));
+        f1 = fminf(f1, fmaxf(l, h));
+        l = fmaf(c.z, az.id, az.c_lo);
+        h = fmaf(c.w, az.id, az.c_hi);
+        n1 = fmaxf(fmaxf(n1, fminf(l, h)), tminf);
+        f1 = fminf(fminf(f1, fmaxf(l, h)), tbestf);
+        const bool h0 = n0 <= f0, h1 = n1 <= f1;
+        if (h0 && h1) {
+            const bool swap = n1 < n0;
+            stk[sp * 64] = (uint32_t)(swap ? refs.x : refs.y);
+            sp++;
+            cur = swap ? refs.y : refs.x;
+        } else if (h0) {
+            cur = refs.x;
+        } else if (h1) {
+            cur = refs.y;
+        } else if (sp == 0) {
+            active = false;
         } else {
-            const uint32_t enc = ~(uint32_t)cur;
-            const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
-            bool stop = false;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                double t, al, be;
-                if (COUNT) wc.tris++;
-                if (tri_test(S.tris + first + i, o, d, tmin, hit.t, t, al, be)) {
-                    hit.t = t;
-                    hit.alpha = al;
-                    hit.beta = be;
-                    hit.tri = (int32_t)(first + i);
-                    tbestf = f32_up(t);
-                    if (t < early_t) stop = true;
-                }
-            }
-            if (stop || sp == 0) break;
             sp--;
             cur = (int32_t)stk[sp * 64];
         }
     }
-}
+
+    // One leaf: fp64 tests of its triangles (128-byte records), then pop.
+    template <bool COUNT>
+    PRT_DEV void leaf_step(const DScene& S, uint32_t* stk, WorkCount& wc) {
+        const uint32_t enc = ~(uint32_t)cur;
+        const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
+        bool stop = false;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            double t, al, be;
+            if (COUNT) wc.tris++;
+            if (tri_test(S.tris + first + i, o, d, tmin, hit.t, t, al, be)) {
+                hit.t = t;
+                hit.alpha = al;
+                hit.beta = be;
+                hit.tri = (int32_t)(first + i);
+                tbestf = f32_up(t);
+                if (t < early) stop = true;
+            }
+        }
+        if (stop || sp == 0) {
+            active = false;
+        } else {
+            sp--;
+            cur = (int32_t)stk[sp * 64];
+        }
+    }
+
+    // One scheduling round of the wave.  Node visits are cheap (4 loads) and run whenever a lane is
+    // at an inner node; leaves are expensive (8 loads per triangle) and the texture addresser charges
+    // a load instruction the same whether 3 or 64 lanes execute it, so lanes that reach a leaf PARK
+    // there until at least PRT_LEAF_BATCH lanes of the wave are parked (or hardly any lane is still
+    // descending), and then test their triangles together.
+    template <bool COUNT>
+    PRT_DEV void round(const DScene& S, uint32_t* stk, WorkCount& wc) {
+        if (active && cur >= 0) inner_step<COUNT>(S, stk, wc);
+        const bool parked = active && cur < 0;
+        const int n_parked = __popcll(__ballot(parked));
+        const int n_inner = __popcll(__ballot(active && cur >= 0));
+        if (n_parked >= PRT_LEAF_BATCH || n_inner <= PRT_INNER_MIN) {
+            if (parked) leaf_step<COUNT>(S, stk, wc);
+        }
+    }
+};
+
+// Number of lanes of the wave for which `p` holds.
+PRT_DEV int wave_count(bool p) { return __popcll(__ballot(p)); }
 
 // ------------------------------------------------------------------ textures (Texture.cpp:22-71)
 PRT_DEV d3 tex_pixel(const DScene& S, const DTexture& tx, int x, int y) {

@@ -11,10 +11,13 @@
 //     (pixel, sample chunk) and pulls the next one from a global atomic counter when it finishes, so
 //     short paths (light / background pixels) never idle a wave for long — lane-level regeneration
 //     instead of a per-bounce compaction pass;
-//   * one loop iteration = ONE traversal per lane — a continuation ray or an NEE shadow ray, whichever
-//     that lane's path needs next — so the whole wave is always inside the same traversal code
-//     (single call site: half the registers of a trace/shade/trace/shade loop) and only the short
-//     shading tails diverge; shadow rays use closest-hit semantics with a certain-occluder early-out;
+//   * traversal is resumable per lane (Trav::step = one node visit or one leaf).  A wave steps all
+//     its traversing lanes together and leaves the stepping loop as soon as only PRT_K3_KEEP of them
+//     are still busy (ballot + popcount); the finished lanes consume their hit (shade / NEE set-up /
+//     Russian roulette / Scatter / next sample / next item) and start their next ray — continuation
+//     or shadow, whichever that path needs — while the others keep their stack and resume.  Lanes
+//     never wait for the slowest ray of the wave, and there is a single traversal call site;
+//     shadow rays use closest-hit semantics with a certain-occluder early-out;
 //   * traversal stack in LDS, lane-strided (conflict-free), PRT_STACK_DEPTH entries per lane;
 //   * results are deterministic: per-sample keyed RNG, per-item partial sums combined in a fixed
 //     order by K5 (no float atomics on the framebuffer).
@@ -25,7 +28,18 @@
 
 // minimum resident waves per SIMD the register allocator must leave room for in K3
 #ifndef PRT_RENDER_WAVES
-#define PRT_RENDER_WAVES 4
+#define PRT_RENDER_WAVES 2
+#endif
+// The stepping loop of a wave runs while MORE than this many lanes are still traversing; below it the
+// finished lanes are handed new rays (K1) / shaded and re-armed (K3).
+#ifndef PRT_K1_KEEP
+#define PRT_K1_KEEP 48
+#endif
+#ifndef PRT_K3_KEEP
+#define PRT_K3_KEEP 24
+#endif
+#ifndef PRT_K1_CHUNK
+#define PRT_K1_CHUNK 1024
 #endif
 
 namespace {
@@ -37,6 +51,9 @@ __device__ __forceinline__ T wave_sum(T v) {
 }
 
 // ------------------------------------------------------------------------------------------- K1
+// Persistent waves; every lane pulls its next ray from a global counter the moment its traversal
+// ends.  The stepping loop is left (and the finished lanes refilled) once no more than
+// PRT_K1_KEEP lanes are still traversing.
 template <bool COUNT>
 __global__ __launch_bounds__(PRT_BLOCK) void k_trace_closest(DScene S, const PrtRay* __restrict__ rays, size_t n,
                                                              PrtHit* __restrict__ hits, DCounters* ctr) {
@@ -45,35 +62,70 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_trace_closest(DScene S, const Prt
     uint32_t* stk = &s_stack[wave][0][lane];
     WorkCount wc{0, 0};
     uint32_t nrays = 0;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const double4* rp = reinterpret_cast<const double4*>(rays + i);
-        double4 r0 = rp[0], r1 = rp[1];
-        d3 o = mk3(r0.x, r0.y, r0.z), d = mk3(r1.x, r1.y, r1.z);
-        HitInfo h;
-        if (S.n_tris == 0) {
-            h.t = r1.w;
-            h.tri = -1;
-            h.alpha = h.beta = 0;
-        } else {
-            trace<COUNT>(S, o, d, r0.w, r1.w, -PRT_INF, h, stk, wc);
+    Trav tr;
+    tr.init(S, mk3(0, 0, 0), mk3(0, 0, 1), 0.0, 0.0, 0.0);
+    tr.active = false;
+    bool have = false;
+    size_t my = 0;
+    // wave-local ray pool [pool_next, pool_end): refilled PRT_K1_CHUNK rays at a time by ONE atomic per
+    // wave (a single global counter saturates at ~90 dequeues/us on this chip)
+    unsigned long long pool_next = 0, pool_end = 0;
+    bool exhausted = false; // wave-uniform
+    for (;;) {
+        if (!tr.active) {
+            if (have) {
+                PrtHit out;
+                if (tr.hit.tri >= 0) {
+                    const DTri* T = S.tris + tr.hit.tri;
+                    const d3 nrm = mk3(T->n[0], T->n[1], T->n[2]);
+                    out.t = tr.hit.t;
+                    out.alpha = tr.hit.alpha;
+                    out.beta = tr.hit.beta;
+                    out.prim = S.shade[tr.hit.tri].prim;
+                    out.front = dot(tr.d, nrm) < 0. ? 1 : 0; // HitRecord::SetFaceNormal, Hittable.cpp:8-13
+                } else {
+                    out.t = PRT_INF;
+                    out.alpha = out.beta = 0;
+                    out.prim = -1;
+                    out.front = 0;
+                }
+                hits[my] = out;
+                have = false;
+            }
         }
-        nrays++;
-        PrtHit out;
-        if (h.tri >= 0) {
-            const DTri* T = S.tris + h.tri;
-            d3 nrm = mk3(T->n[0], T->n[1], T->n[2]);
-            out.t = h.t;
-            out.alpha = h.alpha;
-            out.beta = h.beta;
-            out.prim = S.shade[h.tri].prim;
-            out.front = dot(d, nrm) < 0. ? 1 : 0; // HitRecord::SetFaceNormal, Hittable.cpp:8-13
-        } else {
-            out.t = PRT_INF;
-            out.alpha = out.beta = 0;
-            out.prim = -1;
-            out.front = 0;
+        {
+            const unsigned long long need = __ballot(!tr.active);
+            if (need != 0ULL && !exhausted) {
+                if (pool_next >= pool_end) {
+                    unsigned long long base = 0;
+                    if (lane == (int)__builtin_ctzll(need)) base = atomicAdd(&ctr->next_item, (unsigned long long)PRT_K1_CHUNK);
+                    base = __shfl(base, (int)__builtin_ctzll(need), 64);
+                    pool_next = base;
+                    pool_end = base + PRT_K1_CHUNK < (unsigned long long)n ? base + PRT_K1_CHUNK : (unsigned long long)n;
+                    if (base >= (unsigned long long)n) exhausted = true;
+                }
+                if (!exhausted && !tr.active) {
+                    const unsigned long long below = need & ((1ULL << lane) - 1ULL);
+                    const unsigned long long idx = pool_next + (unsigned long long)__popcll(below);
+                    if (idx < pool_end) {
+                        const double4* rp = reinterpret_cast<const double4*>(rays + idx);
+                        const double4 r0 = rp[0], r1 = rp[1];
+                        tr.init(S, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), r0.w, r1.w, -PRT_INF);
+                        my = (size_t)idx;
+                        have = true;
+                        nrays++;
+                    }
+                }
+                if (!exhausted) {
+                    const unsigned long long taken = (unsigned long long)__popcll(need);
+                    pool_next = pool_next + taken < pool_end ? pool_next + taken : pool_end;
+                }
+            }
         }
-        hits[i] = out;
+        if (__ballot(tr.active || have) == 0ULL && exhausted) break;
+        do {
+            tr.round<COUNT>(S, stk, wc);
+        } while (wave_count(tr.active) > PRT_K1_KEEP);
     }
     unsigned long long a = wave_sum((unsigned long long)nrays);
     unsigned long long b = wave_sum((unsigned long long)wc.nodes);
@@ -115,8 +167,8 @@ PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 ro, d3 rd, const HitInfo& h) {
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(PRT_BLOCK, PRT_RENDER_WAVES) void k_render(DScene S, DCamera C, DRenderParams P, double* __restrict__ partial,
-                                                      DCounters* ctr) {
+__global__ __launch_bounds__(PRT_BLOCK, PRT_RENDER_WAVES) void k_render(DScene S, DCamera C, DRenderParams P,
+                                                                        double* __restrict__ partial, DCounters* ctr) {
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stk = &s_stack[wave][0][lane];
@@ -139,67 +191,16 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_RENDER_WAVES) void k_render(DScene S
     Rng rng;
     rng.s = 0;
     const double inv_spp = 1.0 / P.spp; // pixelSamplesScale, Camera.cpp:83
+    Trav tr;
+    tr.init(S, ro, rd, 0.0, 0.0, 0.0);
+    tr.active = false;
 
     for (;;) {
-        if (state == ST_FETCH) {
-            item = atomicAdd(&ctr->next_item, 1ULL);
-            if (item >= P.n_items) {
-                state = ST_DONE;
-            } else {
-                const uint32_t chunk = (uint32_t)(item / P.items_per_chunk);
-                const uint64_t oi = item % P.items_per_chunk;
-                if (owned_to_pixel(P, C, oi, px, py)) {
-                    s = (int)(((int64_t)chunk * P.spp) / P.chunks);
-                    s_end = (int)(((int64_t)(chunk + 1) * P.spp) / P.chunks);
-                    acc = mk3(0, 0, 0);
-                    if (s < s_end) state = ST_NEW_SAMPLE;
-                    else {
-                        double* o = partial + item * 3;
-                        o[0] = o[1] = o[2] = 0.0;
-                    }
-                }
-            }
-        }
-        if (__ballot(state != ST_DONE) == 0ULL) break;
-
-        if (state == ST_NEW_SAMPLE) {
-            // per-sample stream keyed (seed, j*W+i, s); Camera::GetRay (Camera.cpp:108-117): pixel centre, no jitter
-            rng.seed(P.seed, (uint64_t)py * (uint64_t)C.width + (uint64_t)px, (uint64_t)s);
-            d3 ps = ld3(C.pixel00) + ((double)px) * ld3(C.du) + ((double)py) * ld3(C.dv);
-            ro = ld3(C.center);
-            rd = ps - ro;
-            L = mk3(0, 0, 0);
-            beta = mk3(1, 1, 1);
-            depth = P.max_depth;
-            first = true;
-            prev_skip = false;
-            n_samples++;
-            state = ST_CLOSEST;
-        }
-
-        if (state == ST_CLOSEST || state == ST_SHADOW) {
-            // ---- one traversal per lane per iteration: continuation ray or NEE shadow ray
-            d3 to = ro, td = rd;
-            double tmin = 0.0001, tmax = PRT_INF, early = -PRT_INF, dist = 0.0; // Camera.cpp:125
-            if (state == ST_SHADOW) {
-                // Ray(ps, normalize(pl-ps)), Interval(0.001, DBL_MAX) (Camera.cpp:143-150).  Any hit nearer
-                // than dist-1e-3 (minus a safety margin) proves occlusion, so traversal may stop there.
-                to = ro + rd * sh.t;
-                const d3 toL = lpos - to;
-                td = normalize(toL);
-                dist = length(toL);
-                tmin = 0.001;
-                tmax = 1.7976931348623157e308;
-                early = dist - 0.001 - 1e-6;
-                n_shadow++;
-            } else {
-                n_closest++;
-            }
-            HitInfo h;
-            trace<COUNT>(S, to, td, tmin, tmax, early, h, stk, wc);
-
+        if (!tr.active) {
+            // ---------------- a traversal has just finished on this lane: consume its result
             bool end_sample = false, do_scatter = false;
             if (state == ST_CLOSEST) {
+                const HitInfo h = tr.hit;
                 if (h.tri < 0) {
                     // miss: background for the camera ray (Camera.cpp:127); with bSampleLights a bounce miss adds 0 (:187)
                     if (first || !P.sample_lights) L = L + beta * ld3(P.background);
@@ -221,18 +222,20 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_RENDER_WAVES) void k_render(DScene S
                             if (dot(c.f.n, ldir) > 0.0 && lp.front) {
                                 lpos = lp.pos;
                                 ltri = lp.tri;
-                                state = ST_SHADOW; // trace the shadow ray next iteration, then scatter
+                                state = ST_SHADOW; // trace the shadow ray, then scatter
                                 do_scatter = false;
                             }
                         }
                     }
                 }
-            } else {
+            } else if (state == ST_SHADOW) {
                 // ---- shadow ray returned: visibility = closest hit no nearer than dist - 1e-3 (Camera.cpp:152-155)
                 const ShadeCtx c = make_ctx(S, ro, rd, sh);
+                const d3 to = tr.o, td = tr.d;
+                const double dist = length(lpos - to);
                 bool visible = true; // an escaping shadow ray counts as unoccluded
-                if (h.tri >= 0) {
-                    const d3 pn = to + td * h.t;
+                if (tr.hit.tri >= 0) {
+                    const d3 pn = to + td * tr.hit.t;
                     visible = (dist - length(to - pn)) < 0.001;
                 }
                 if (visible) {
@@ -292,7 +295,60 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_RENDER_WAVES) void k_render(DScene S
                     state = ST_FETCH;
                 }
             }
+
+            // ---------------- give the lane its next piece of work
+            if (state == ST_FETCH) {
+                item = atomicAdd(&ctr->next_item, 1ULL);
+                if (item >= P.n_items) {
+                    state = ST_DONE;
+                } else {
+                    const uint32_t chunk = (uint32_t)(item / P.items_per_chunk);
+                    const uint64_t oi = item % P.items_per_chunk;
+                    if (owned_to_pixel(P, C, oi, px, py)) {
+                        s = (int)(((int64_t)chunk * P.spp) / P.chunks);
+                        s_end = (int)(((int64_t)(chunk + 1) * P.spp) / P.chunks);
+                        acc = mk3(0, 0, 0);
+                        if (s < s_end) state = ST_NEW_SAMPLE;
+                        else {
+                            double* o = partial + item * 3;
+                            o[0] = o[1] = o[2] = 0.0;
+                        }
+                    }
+                }
+            }
+            if (state == ST_NEW_SAMPLE) {
+                // per-sample stream keyed (seed, j*W+i, s); Camera::GetRay (Camera.cpp:108-117): pixel centre, no jitter
+                rng.seed(P.seed, (uint64_t)py * (uint64_t)C.width + (uint64_t)px, (uint64_t)s);
+                const d3 ps = ld3(C.pixel00) + ((double)px) * ld3(C.du) + ((double)py) * ld3(C.dv);
+                ro = ld3(C.center);
+                rd = ps - ro;
+                L = mk3(0, 0, 0);
+                beta = mk3(1, 1, 1);
+                depth = P.max_depth;
+                first = true;
+                prev_skip = false;
+                n_samples++;
+                state = ST_CLOSEST;
+            }
+            // ---------------- start the traversal this lane needs next
+            if (state == ST_CLOSEST) {
+                n_closest++;
+                tr.init(S, ro, rd, 0.0001, PRT_INF, -PRT_INF); // Camera.cpp:125
+            } else if (state == ST_SHADOW) {
+                // Ray(ps, normalize(pl-ps)), Interval(0.001, DBL_MAX) (Camera.cpp:143-150).  Any hit nearer
+                // than dist-1e-3 (minus a safety margin) proves occlusion, so traversal may stop there.
+                const d3 to = ro + rd * sh.t;
+                const d3 toL = lpos - to;
+                n_shadow++;
+                tr.init(S, to, normalize(toL), 0.001, 1.7976931348623157e308, length(toL) - 0.001 - 1e-6);
+            }
         }
+        if (__ballot(state != ST_DONE) == 0ULL) break;
+
+        // ---------------- traversal steps until enough lanes have finished to be worth refilling
+        do {
+            tr.round<COUNT>(S, stk, wc);
+        } while (wave_count(tr.active) > PRT_K3_KEEP);
     }
 
     unsigned long long a = wave_sum((unsigned long long)n_closest);
@@ -385,7 +441,7 @@ void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hit
                   int n_cu, hipStream_t st) {
     if (n == 0) return;
     size_t want = (n + PRT_BLOCK - 1) / PRT_BLOCK;
-    unsigned grid = (unsigned)std::min<size_t>(want, (size_t)n_cu * 8);
+    unsigned grid = (unsigned)std::min<size_t>(want, (size_t)n_cu * 5); // 5 x 32 KB LDS stacks per CU
     if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(PRT_BLOCK), 0, st, S, d_rays, n, d_hits, d_ctr);
     else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(PRT_BLOCK), 0, st, S, d_rays, n, d_hits, d_ctr);
 }
