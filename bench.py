@@ -95,7 +95,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from pooraytracer_amd import api, build, scenes
+    from pooraytracer_amd import api, build, distributed, scenes
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
@@ -121,8 +121,7 @@ def main():
 
     def step():
         sc.render_device(None, fb.data_ptr(), stream=stream, **render_kw)
-        if nranks > 1:
-            dist.reduce(fb, dst=0, op=dist.ReduceOp.SUM)
+        distributed.reduce_framebuffer(fb, dst=0)
 
     def fence():
         if nranks > 1:

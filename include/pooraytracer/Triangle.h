@@ -23,6 +23,7 @@ public:
     std::array<vec2, 3> texCoords;
     std::array<vec3, 3> vertexNormals; // degenerate-face fallback only (Triangle.cpp:21-29)
     vec3 normal;
+    vec3 tangent;
     double area;
     AABB bbox;
     std::shared_ptr<Material> material;

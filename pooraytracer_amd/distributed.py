@@ -1,0 +1,29 @@
+"""Multi-GPU sharding of one frame: image tiles dealt round-robin over ranks, one
+reduce(sum) of the float framebuffer to rank 0.  Works with any torch.distributed backend
+(nccl = RCCL over xGMI on the GPUs; gloo in the CPU tests).  No data-path collective other than
+the final reduce: tiles are independent, every rank holds the whole (small) scene.
+"""
+import numpy as np
+
+
+def tile_owner_map(width, height, tile=32, nranks=1):
+    """(H,W) int array: rank that renders each pixel.  Mirrors the device mapping in
+    csrc/prt_device.h owned_to_pixel(): tile k = ty*tiles_x + tx belongs to rank k % nranks."""
+    tile = max(8, (tile + 7) // 8 * 8)
+    tiles_x = (width + tile - 1) // tile
+    ty, tx = np.mgrid[0:height, 0:width]
+    k = (ty // tile) * tiles_x + (tx // tile)
+    return (k % nranks).astype(np.int32)
+
+
+def owned_mask(width, height, tile, rank, nranks):
+    return tile_owner_map(width, height, tile, nranks) == rank
+
+
+def reduce_framebuffer(fb, dst=0):
+    """Sum the per-rank framebuffers onto `dst`.  Disjoint tiles => every element is x + 0 + ... + 0,
+    so the result is bit-identical to a single-rank render whatever the reduction order."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
+    return fb

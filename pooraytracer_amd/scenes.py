@@ -391,3 +391,29 @@ def mixed_materials(width=48, height=48) -> SceneData:
     b.mesh("debugPatch", debug, *quad((0.5, -0.3, -0.999), (0.8, -0.3, -0.999), (0.8, 0.0, -0.999), (0.5, 0.0, -0.999)))
     cam = Camera(width, height, 60.0, eye=(0.0173, 0.0091, 0.95), look_at=(0.0, -0.2, 0.0))
     return b.build(cam)
+
+
+def dump_scene(scene: SceneData, path: str):
+    """Flat binary dump read by examples/render_scene.cpp (the C++ host-API driver)."""
+    import struct
+    with open(path, "wb") as f:
+        cam = scene.camera
+        f.write(struct.pack("<Iii d", 0x50525431, cam.width, cam.height, cam.fovy))
+        f.write(struct.pack("<9d", *cam.eye, *cam.look_at, *cam.up))
+        f.write(struct.pack("<I", len(scene.textures)))
+        for t in scene.textures:
+            t = np.ascontiguousarray(t, dtype=np.uint8)
+            f.write(struct.pack("<iii", t.shape[1], t.shape[0], t.shape[2] if t.ndim == 3 else 1))
+            f.write(t.tobytes())
+        f.write(struct.pack("<I", len(scene.materials)))
+        for m in scene.materials:
+            f.write(struct.pack("<ii", m.type, m.texture))
+            f.write(struct.pack("<18d", *m.kd, *m.ks, m.ns, *m.emission, *m.eta, *m.k, m.alpha_x, m.alpha_y))
+        f.write(struct.pack("<I", len(scene.mesh_material)))
+        for i, mat in enumerate(scene.mesh_material):
+            name = scene.mesh_names[i].encode()
+            a, b = int(scene.mesh_first_tri[i]), int(scene.mesh_first_tri[i + 1])
+            f.write(struct.pack("<I", len(name)) + name + struct.pack("<iQ", int(mat), b - a))
+            rec = np.concatenate([scene.vertices[a:b].reshape(b - a, 9), scene.normals[a:b].reshape(b - a, 9),
+                                  scene.texcoords[a:b].reshape(b - a, 6)], axis=1)
+            f.write(np.ascontiguousarray(rec, dtype=np.float64).tobytes())
