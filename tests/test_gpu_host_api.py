@@ -61,14 +61,12 @@ def test_device_tile_mapping_matches_host_owner_map(gpu):
     data = scenes.tiny_scene()
     cam = scenes.Camera(100, 72, 40.0, (0.01, 0.02, 3.4), (0, 0, 0))
     sc = api.Scene(data).upload(gpu)
+    full = sc.render(camera=cam, spp=1, max_depth=0, background=(1.0, 1.0, 1.0), sample_lights=False)
     for tile, n in [(16, 3), (32, 4), (8, 5)]:
         owner = distributed.tile_owner_map(100, 72, tile, n)
         for r in range(n):
             part = sc.render(camera=cam, spp=1, max_depth=0, background=(1.0, 1.0, 1.0), sample_lights=False,
                              tile_size=tile, rank=r, nranks=n)
-            # depth 0, white background: a rendered pixel is either background (1) or a surface; other ranks' pixels are 0
-            rendered = np.zeros((72, 100), bool)
-            full = sc.render(camera=cam, spp=1, max_depth=0, background=(1.0, 1.0, 1.0), sample_lights=False)
-            rendered = (part == full).all(-1) & (full != 0).any(-1)
-            assert np.array_equal(rendered | ((full == 0).all(-1) & (owner == r)), owner == r) or \
-                np.array_equal((part != 0).any(-1), (owner == r) & (full != 0).any(-1))
+            mine = owner == r
+            assert np.array_equal(part[mine], full[mine])      # owned pixels: the single-rank values
+            assert (part[~mine] == 0).all()                     # everything else stays zero
