@@ -57,11 +57,18 @@ inline float round_up(double v) {
     return f;
 }
 
+// builder-side node: fp32 outward-rounded child boxes, converted to the device format at the end
+struct FNode {
+    float c0x[2], c0y[2], c0z[2];
+    float c1x[2], c1y[2], c1z[2];
+    int32_t ref0, ref1;
+};
+
 struct Builder {
     std::vector<PrimRef> prims;
-    std::vector<DNode>& nodes;
+    std::vector<FNode>& nodes;
     uint32_t max_depth = 0;
-    explicit Builder(std::vector<DNode>& n) : nodes(n) {}
+    explicit Builder(std::vector<FNode>& n) : nodes(n) {}
 
     static int32_t leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | (count - 1)); }
 
@@ -167,7 +174,7 @@ struct Builder {
         FBox b0, b1;
         const int32_t r0 = build(s, mid, levels - 1, depth + 1, b0, false);
         const int32_t r1 = build(mid, e, levels - 1, depth + 1, b1, false);
-        DNode& n = nodes[me];
+        FNode& n = nodes[me];
         n.c0x[0] = b0.lo[0]; n.c0x[1] = b0.hi[0];
         n.c0y[0] = b0.lo[1]; n.c0y[1] = b0.hi[1];
         n.c0z[0] = b0.lo[2]; n.c0z[1] = b0.hi[2];
@@ -176,7 +183,6 @@ struct Builder {
         n.c1z[0] = b1.lo[2]; n.c1z[1] = b1.hi[2];
         n.ref0 = r0;
         n.ref1 = r1;
-        n.pad[0] = n.pad[1] = 0;
         return me;
     }
 };
@@ -192,14 +198,14 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
         if (err) *err = "too many triangles for the 28-bit leaf encoding";
         return false;
     }
-    if (n == 0) { // trace() short-circuits on n_tris == 0; keep a well-formed root anyway
-        DNode z;
+    std::vector<FNode> fn;
+    if (n == 0) { // traversal short-circuits on n_tris == 0; keep a well-formed root anyway
+        FNode z;
         std::memset(&z, 0, sizeof(z));
         z.ref0 = z.ref1 = ~0;
-        out.nodes.push_back(z);
-        return true;
+        fn.push_back(z);
     }
-    Builder b(out.nodes);
+    Builder b(fn);
     b.prims.resize(n);
     // small absolute inflation on top of the outward rounding (the kernel adds its own per-ray pad)
     double scale = 1.0;
@@ -214,27 +220,83 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
         b.prims[i].idx = (uint32_t)i;
     }
     FBox root;
+    root.reset();
     if (n == 1) {
         // one triangle: the root tests it through both children (like the reference's span-1 node, BVH.cpp:21-23)
         b.range_box(0, 1, root);
-        DNode r;
+        FNode r;
         std::memset(&r, 0, sizeof(r));
         r.c0x[0] = r.c1x[0] = root.lo[0]; r.c0x[1] = r.c1x[1] = root.hi[0];
         r.c0y[0] = r.c1y[0] = root.lo[1]; r.c0y[1] = r.c1y[1] = root.hi[1];
         r.c0z[0] = r.c1z[0] = root.lo[2]; r.c0z[1] = r.c1z[1] = root.hi[2];
         r.ref0 = r.ref1 = Builder::leaf_ref(0, 1);
-        out.nodes.push_back(r);
-    } else {
-        out.nodes.reserve(n);
+        fn.push_back(r);
+    } else if (n > 1) {
+        fn.reserve(n);
         b.build(0, (uint32_t)n, kMaxLevels, 0, root, true);
     }
     out.depth = b.max_depth;
     float cs = 0.f;
     for (const PrimRef& pr : b.prims)
         for (int a = 0; a < 3; ++a) cs = std::max(cs, std::max(std::fabs(pr.lo[a]), std::fabs(pr.hi[a])));
-    out.coord_scale = std::nextafter(cs, std::numeric_limits<float>::infinity());
+    out.coord_scale = n ? std::nextafter(cs, std::numeric_limits<float>::infinity()) : 1.0f;
     out.order.resize(n);
     for (size_t i = 0; i < n; ++i) out.order[i] = b.prims[i].idx;
+
+    out.nodes.resize(fn.size());
+#if PRT_NODE16
+    // quantisation grid over the root box: coordinate(q) = g0 + q * gs, evaluated in double here; the
+    // kernel's float evaluation error is covered by its per-ray pad.  lo rounds down, hi rounds up.
+    double g0[3], gs[3];
+    for (int a = 0; a < 3; ++a) {
+        const double lo = n ? (double)root.lo[a] : 0.0, hi = n ? (double)root.hi[a] : 1.0;
+        const float o = round_down(lo);
+        float st = round_up((hi - (double)o) / 65535.0);
+        if (!(st > 0.f)) st = std::numeric_limits<float>::min();
+        while ((double)o + 65535.0 * (double)st < hi) st = std::nextafter(st, std::numeric_limits<float>::infinity());
+        out.grid_origin[a] = o;
+        out.grid_step[a] = st;
+        g0[a] = o;
+        gs[a] = st;
+    }
+    auto qlo = [&](float v, int a) -> uint16_t {
+        double q = std::floor(((double)v - g0[a]) / gs[a]);
+        q = std::min(65535.0, std::max(0.0, q));
+        while (q > 0 && g0[a] + q * gs[a] > (double)v) q -= 1;
+        return (uint16_t)q;
+    };
+    auto qhi = [&](float v, int a) -> uint16_t {
+        double q = std::ceil(((double)v - g0[a]) / gs[a]);
+        q = std::min(65535.0, std::max(0.0, q));
+        while (q < 65535 && g0[a] + q * gs[a] < (double)v) q += 1;
+        return (uint16_t)q;
+    };
+    for (size_t i = 0; i < fn.size(); ++i) {
+        const FNode& f = fn[i];
+        DNode& d = out.nodes[i];
+        d.c0x[0] = qlo(f.c0x[0], 0); d.c0x[1] = qhi(f.c0x[1], 0);
+        d.c0y[0] = qlo(f.c0y[0], 1); d.c0y[1] = qhi(f.c0y[1], 1);
+        d.c0z[0] = qlo(f.c0z[0], 2); d.c0z[1] = qhi(f.c0z[1], 2);
+        d.c1x[0] = qlo(f.c1x[0], 0); d.c1x[1] = qhi(f.c1x[1], 0);
+        d.c1y[0] = qlo(f.c1y[0], 1); d.c1y[1] = qhi(f.c1y[1], 1);
+        d.c1z[0] = qlo(f.c1z[0], 2); d.c1z[1] = qhi(f.c1z[1], 2);
+        d.ref0 = f.ref0;
+        d.ref1 = f.ref1;
+    }
+    float gm = 0.f; // the dequantised coordinates can exceed the fp32 boxes by one grid step
+    for (int a = 0; a < 3; ++a)
+        gm = std::max(gm, std::max(std::fabs(out.grid_origin[a]), std::fabs((float)(g0[a] + 65535.0 * gs[a]))));
+    out.coord_scale = std::nextafter(std::max(out.coord_scale, gm), std::numeric_limits<float>::infinity());
+#else
+    for (size_t i = 0; i < fn.size(); ++i) {
+        const FNode& f = fn[i];
+        DNode& d = out.nodes[i];
+        std::memset(&d, 0, sizeof(d));
+        std::memcpy(d.c0x, f.c0x, sizeof(float) * 12);
+        d.ref0 = f.ref0;
+        d.ref1 = f.ref1;
+    }
+#endif
     return true;
 }
 

@@ -14,11 +14,11 @@
 #include "prt_host.h"
 
 namespace prt {
-int render_blocks_per_cu(bool count);
+int render_blocks_per_cu(bool count, bool full);
 void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hits, DCounters* d_ctr, bool count, int n_cu,
                   hipStream_t st);
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
-                   bool count, unsigned grid, hipStream_t st);
+                   bool count, bool full, unsigned grid, hipStream_t st);
 void launch_finalize(const DCamera& C, const DRenderParams& P, const double* d_partial, double* d64, float* d32,
                      hipStream_t st);
 void launch_sample_lights(const DScene& S, const double* d_origins, size_t n, uint64_t seed, PrtLightSample* d_out,
@@ -54,6 +54,7 @@ struct PrtScene {
     int device = -1;
     int n_cu = 0;
     int blocks_per_cu[2] = {0, 0};
+    bool full_materials = false; // needs the Phong / CookTorrance / texture kernel permutation
     DScene d{};
     std::vector<void*> allocs;
     DCounters* d_ctr = nullptr;
@@ -244,12 +245,19 @@ int prt_scene_upload(PrtScene* s, int device) {
     d.n_nodes = (uint32_t)s->bvh.nodes.size();
     d.n_tris = (uint32_t)n;
     d.coord_scale = s->bvh.coord_scale;
+    for (int a = 0; a < 3; ++a) {
+        d.grid_origin[a] = s->bvh.grid_origin[a];
+        d.grid_step[a] = s->bvh.grid_step[a];
+    }
     PRT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_ctr), sizeof(DCounters)));
     PRT_HIP(hipMemset(s->d_ctr, 0, sizeof(DCounters)));
     PRT_HIP(hipEventCreate(&s->ev0));
     PRT_HIP(hipEventCreate(&s->ev1));
-    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false);
-    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true);
+    s->full_materials = false;
+    for (const DMaterial& m : s->mats)
+        if (m.type == PRT_MAT_PHONG || m.type == PRT_MAT_COOKTORRANCE || m.texture >= 0) s->full_materials = true;
+    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->full_materials);
+    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->full_materials);
     return PRT_OK;
 }
 
@@ -346,6 +354,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.max_depth = p->max_depth;
     P.sample_lights = p->sample_lights ? 1 : 0;
     P.rr = p->russian_roulette;
+    P.inv_rr = 1.0 / p->russian_roulette;
     for (int c = 0; c < 3; ++c) P.background[c] = p->background[c];
     P.seed = p->seed;
     int tile = p->tile_size > 0 ? p->tile_size : 32;
@@ -386,7 +395,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     if (P.n_items) {
         const uint64_t want = (P.n_items + PRT_BLOCK - 1) / PRT_BLOCK;
         const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)s->n_cu * bpc));
-        prt::launch_render(s->d, C, P, s->d_partial, s->d_ctr, count, grid, st);
+        prt::launch_render(s->d, C, P, s->d_partial, s->d_ctr, count, s->full_materials, grid, st);
         PRT_HIP(hipGetLastError());
     }
     PRT_HIP(hipEventRecord(s->ev1, st));

@@ -39,6 +39,11 @@ PRT_DEV double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PRT_DEV d3 cross(d3 x, d3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
 PRT_DEV double length(d3 v) { return sqrt(dot(v, v)); }
 PRT_DEV d3 normalize(d3 v) { return v * (1.0 / sqrt(dot(v, v))); }
+// normalize(v) and length(v) from one sqrt — the same values as glm::normalize / glm::length
+PRT_DEV d3 normalize_len(d3 v, double& len) {
+    len = sqrt(dot(v, v));
+    return v * (1.0 / len);
+}
 
 #define PRT_PI 3.14159265358979323846
 #define PRT_INV_PI 0.31830988618379067154
@@ -120,22 +125,24 @@ PRT_DEV float f32_down(double x) {
     return f - fabsf(f) * 2.4e-7f;
 }
 
-// Per-ray constants of the fp32 slab test  t(b) = fma(b, id, c):  id ~ 1/d, c = -o*id, with the
-// rounding of o, 1/d, the product and the fma (<= 6 * 2^-24 * (|o|+B) * |id| in t, B = largest box
-// coordinate) covered by pad = 2^-21 * (|o|+B) * |id|, subtracted on the entry plane and added on the
-// exit plane.  |id| is clamped to 1e28 so a zero direction component never produces inf - inf.
+// Per-ray constants of the fp32 slab test.  A box plane at coordinate b = g0 + q*gs (q = the node's
+// 16-bit grid index; gs = 1, g0 = 0 for fp32 nodes) is crossed at t(q) = fma(q, idq, c) with
+// idq = gs*id, id ~ 1/d (v_rcp_f32, 1 ulp), c = (g0 - o)*id.  The roundings of o, 1/d, gs*id, the
+// subtraction, the product and the fma sum to <= 9 * 2^-24 * (|o|+B) * |id| in t (B = largest box
+// coordinate); pad = 2^-20 * (|o|+B) * |id| covers them, subtracted on the entry plane and added on
+// the exit plane.  |id| is clamped to 1e28 so a zero direction component never yields inf - inf.
 struct SlabAxis {
-    float id, c_lo, c_hi;
+    float idq, c_lo, c_hi;
 };
-PRT_DEV SlabAxis slab_axis(double o, double d, float B) {
+PRT_DEV SlabAxis slab_axis(double o, double d, float B, float g0, float gs) {
     SlabAxis a;
     const float df = (float)d;
-    float id = 1.0f / df;
+    float id = __builtin_amdgcn_rcpf(df);
     if (!(fabsf(id) <= 1e28f)) id = copysignf(1e28f, df);
     const float of = (float)o;
-    const float c = -of * id;
-    const float pad = fabsf(id) * (fabsf(of) + B) * 4.76837158e-7f;
-    a.id = id;
+    const float c = (g0 - of) * id;
+    const float pad = fabsf(id) * (fabsf(of) + B) * 9.5367432e-7f;
+    a.idq = gs * id;
     a.c_lo = id >= 0.f ? c - pad : c + pad; // the lo plane is the entry plane when id >= 0
     a.c_hi = id >= 0.f ? c + pad : c - pad;
     return a;
@@ -167,9 +174,15 @@ struct Trav {
         d = d_;
         tmin = tmin_;
         early = early_;
-        ax = slab_axis(o.x, d.x, S.coord_scale);
-        ay = slab_axis(o.y, d.y, S.coord_scale);
-        az = slab_axis(o.z, d.z, S.coord_scale);
+#if PRT_NODE16
+        ax = slab_axis(o.x, d.x, S.coord_scale, S.grid_origin[0], S.grid_step[0]);
+        ay = slab_axis(o.y, d.y, S.coord_scale, S.grid_origin[1], S.grid_step[1]);
+        az = slab_axis(o.z, d.z, S.coord_scale, S.grid_origin[2], S.grid_step[2]);
+#else
+        ax = slab_axis(o.x, d.x, S.coord_scale, 0.f, 1.f);
+        ay = slab_axis(o.y, d.y, S.coord_scale, 0.f, 1.f);
+        az = slab_axis(o.z, d.z, S.coord_scale, 0.f, 1.f);
+#endif
         tminf = f32_down(tmin_);
         tbestf = f32_up(tmax_);
         hit.t = tmax_;
@@ -184,31 +197,47 @@ struct Trav {
     // One inner-node visit: fetch the 64-byte node, test both child boxes, descend / push / pop.
     template <bool COUNT>
     PRT_DEV void inner_step(const DScene& S, uint32_t* stk, WorkCount& wc) {
+#if PRT_NODE16
+        // 32-byte node = two 16-byte loads: 12 x u16 grid indices (lo,hi pairs) + 2 refs
+        const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
+        const uint4 w0 = np[0], w1 = np[1];
+        float4 a, b, c;
+        a.x = (float)(w0.x & 0xffffu); a.y = (float)(w0.x >> 16);
+        a.z = (float)(w0.y & 0xffffu); a.w = (float)(w0.y >> 16);
+        b.x = (float)(w0.z & 0xffffu); b.y = (float)(w0.z >> 16);
+        b.z = (float)(w0.w & 0xffffu); b.w = (float)(w0.w >> 16);
+        c.x = (float)(w1.x & 0xffffu); c.y = (float)(w1.x >> 16);
+        c.z = (float)(w1.y & 0xffffu); c.w = (float)(w1.y >> 16);
+        int2 refs;
+        refs.x = (int)w1.z;
+        refs.y = (int)w1.w;
+#else
         const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
         const float4 a = np[0], b = np[1], c = np[2];
         const int2 refs = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(S.nodes + cur) + 48);
+#endif
         if (COUNT) wc.nodes++;
         // child 0: a = (lo.x,hi.x,lo.y,hi.y), b.xy = (lo.z,hi.z)
-        float l = fmaf(a.x, ax.id, ax.c_lo), h = fmaf(a.y, ax.id, ax.c_hi);
+        float l = fmaf(a.x, ax.idq, ax.c_lo), h = fmaf(a.y, ax.idq, ax.c_hi);
         float n0 = fminf(l, h), f0 = fmaxf(l, h);
-        l = fmaf(a.z, ay.id, ay.c_lo);
-        h = fmaf(a.w, ay.id, ay.c_hi);
+        l = fmaf(a.z, ay.idq, ay.c_lo);
+        h = fmaf(a.w, ay.idq, ay.c_hi);
         n0 = fmaxf(n0, fminf(l, h));
         f0 = fminf(f0, fmaxf(l, h));
-        l = fmaf(b.x, az.id, az.c_lo);
-        h = fmaf(b.y, az.id, az.c_hi);
+        l = fmaf(b.x, az.idq, az.c_lo);
+        h = fmaf(b.y, az.idq, az.c_hi);
         n0 = fmaxf(fmaxf(n0, fminf(l, h)), tminf);
         f0 = fminf(fminf(f0, fmaxf(l, h)), tbestf);
         // child 1: b.zw = (lo.x,hi.x), c = (lo.y,hi.y,lo.z,hi.z)
-        l = fmaf(b.z, ax.id, ax.c_lo);
-        h = fmaf(b.w, ax.id, ax.c_hi);
+        l = fmaf(b.z, ax.idq, ax.c_lo);
+        h = fmaf(b.w, ax.idq, ax.c_hi);
         float n1 = fminf(l, h), f1 = fmaxf(l, h);
-        l = fmaf(c.x, ay.id, ay.c_lo);
-        h = fmaf(c.y, ay.id, ay.c_hi);
+        l = fmaf(c.x, ay.idq, ay.c_lo);
+        h = fmaf(c.y, ay.idq, ay.c_hi);
         n1 = fmaxf(n1, fminf(l, h));
         f1 = fminf(f1, fmaxf(l, h));
-        l = fmaf(c.z, az.id, az.c_lo);
-        h = fmaf(c.w, az.id, az.c_hi);
+        l = fmaf(c.z, az.idq, az.c_lo);
+        h = fmaf(c.w, az.idq, az.c_hi);
         n1 = fmaxf(fmaxf(n1, fminf(l, h)), tminf);
         f1 = fminf(fminf(f1, fmaxf(l, h)), tbestf);
         const bool h0 = n0 <= f0, h1 = n1 <= f1;
@@ -427,26 +456,35 @@ PRT_DEV d3 ct_sample_wm(const DMaterial& m, d3 w, d2 u) { // Material.h:412-435
 
 // ------------------------------------------------------------------ Material::Eval for NEE
 // Lambertian Material.h:128-130; Phong :227-248 (draws one uniform); CookTorrance :474-496.
+// FULL = false is the lean kernel permutation for scenes whose materials are only Lambertian /
+// DiffuseLight / PerfectMirror / Debug / Empty with solid colours (chosen per scene by the host):
+// Phong, CookTorrance and image textures are compiled out, which is worth a wave of occupancy.
+template <bool FULL>
 PRT_DEV d3 mat_kd(const DScene& S, const DMaterial& m, d2 uv) {
-    return m.texture >= 0 ? tex_value(S, m.texture, uv.x, uv.y) : ld3(m.kd);
+    if (FULL && m.texture >= 0) return tex_value(S, m.texture, uv.x, uv.y);
+    return ld3(m.kd);
 }
+template <bool FULL>
 PRT_DEV d3 mat_ks(const DScene& S, const DMaterial& m, d2 uv) { // Phong(mapKd,...) stores the map in Ks too (:178-181)
-    return m.texture >= 0 ? tex_value(S, m.texture, uv.x, uv.y) : ld3(m.ks);
+    if (FULL && m.texture >= 0) return tex_value(S, m.texture, uv.x, uv.y);
+    return ld3(m.ks);
 }
+template <bool FULL>
 PRT_DEV d3 mat_eval(const DScene& S, const DMaterial& m, d3 wi, d3 wo, d2 uv, Rng& rng) {
+    if (!FULL) return m.type == 0 ? ld3(m.kd) * PRT_INV_PI : mk3(0, 0, 0);
     switch (m.type) {
-    case 0: return mat_kd(S, m, uv) * PRT_INV_PI;
+    case 0: return mat_kd<FULL>(S, m, uv) * PRT_INV_PI;
     case 1: {
         double u = rng.next();
         if (u < m.pkd) {
             if (wi.z <= 0) return mk3(0, 0, 0);
-            return mat_kd(S, m, uv) * PRT_INV_PI;
+            return mat_kd<FULL>(S, m, uv) * PRT_INV_PI;
         } else if (m.pkd <= u && u < m.pkd + m.pks) {
             if (wi.z <= 0) return mk3(0, 0, 0);
             d3 lr = normalize(reflect_z(wo));
             double ca = fmax(0., dot(wi, lr));
             if (ca <= 0.) return mk3(0, 0, 0);
-            return mat_ks(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pow(ca, m.ns);
+            return mat_ks<FULL>(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pow(ca, m.ns);
         }
         return mk3(0, 0, 0);
     }
@@ -467,16 +505,18 @@ PRT_DEV d3 mat_eval(const DScene& S, const DMaterial& m, d3 wi, d3 wo, d2 uv, Rn
 // ------------------------------------------------------------------ Material::Scatter
 // Returns false when the reference's Scatter returns false.  `wi_world` is the (normalised) scattered
 // direction, `att` = f * cos / pdf.  rd = incoming ray direction (unnormalised for camera rays).
+template <bool FULL>
 PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame& f, d2 uv, Rng& rng, d3& att,
                          d3& wi_world) {
+    if (!FULL && m.type != 0 && m.type != 2) return false;
     switch (m.type) {
     case 0: { // Lambertian, Material.h:106-151
         d3 wi = cosine_hemisphere(rng);
         while (wi.z <= 0.) wi = cosine_hemisphere(rng);
         double pdf = wi.z * PRT_INV_PI;
-        d3 fr = mat_kd(S, m, uv) * PRT_INV_PI;
+        d3 fr = mat_kd<FULL>(S, m, uv) * PRT_INV_PI;
         wi_world = local_to_world(wi, f);
-        att = fr * wi.z / pdf;
+        att = (fr * wi.z) * (1.0 / pdf); // fr*cos/pdf with one reciprocal (last-bit rounding only)
         return true;
     }
     case 1: { // PhoneReflectance, Material.h:183-285
@@ -488,7 +528,7 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
             wi = cosine_hemisphere(rng);
             while (wi.z <= 0.) wi = cosine_hemisphere(rng);
             pdf = wi.z * PRT_INV_PI;
-            fr = mat_kd(S, m, uv) * PRT_INV_PI;
+            fr = mat_kd<FULL>(S, m, uv) * PRT_INV_PI;
         } else if (m.pkd <= u && u < m.pkd + m.pks) {
             double u1 = rng.next(), u2 = rng.next();
             double alpha = acos(pow(u1, 1.0 / (m.ns + 1.0)));
@@ -507,7 +547,7 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
             if (wi.z <= 0.) pdf = 0.0;
             else pdf = (m.ns + 1.0) * PRT_INV_2PI * pow(dot(wi, lr), m.ns);
             double lca = fmax(0.0, dot(wi, lr));
-            if (wi.z > 0. && lca > 0.) fr = mat_ks(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pow(lca, m.ns);
+            if (wi.z > 0. && lca > 0.) fr = mat_ks<FULL>(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pow(lca, m.ns);
         }
         wi_world = local_to_world(wi, f);
         if (pdf > 0. && wi.z > 0) att = fr * wi.z / pdf;
@@ -577,10 +617,7 @@ PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng) {
     d3 dir = lp.pos - origin;
     lp.front = dot(dir, n) < 0.;
     lp.n = lp.front ? n : -n;
-    double pdf = 1.0 / lt->area;
-    pdf *= lt->area;
-    pdf /= S.light_area;
-    lp.pdf = pdf;
+    lp.pdf = lt->pdf; // (1/area)*area/total_area, evaluated in that order on the host
     return lp;
 }
 

@@ -26,6 +26,7 @@ struct BuiltBVH {
     std::vector<uint32_t> order; // BVH leaf order -> index into the HostTri array
     uint32_t depth = 0;
     float coord_scale = 1.0f;    // >= |every box coordinate|
+    float grid_origin[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1}; // PRT_NODE16 quantisation grid
 };
 
 struct LightTree {

@@ -30,6 +30,9 @@
 #ifndef PRT_RENDER_WAVES
 #define PRT_RENDER_WAVES 2
 #endif
+#ifndef PRT_RENDER_WAVES_LEAN
+#define PRT_RENDER_WAVES_LEAN 3 // the lean material permutation fits one more wave per SIMD
+#endif
 // The stepping loop of a wave runs while MORE than this many lanes are still traversing; below it the
 // finished lanes are handed new rays (K1) / shaded and re-armed (K3).
 #ifndef PRT_K1_KEEP
@@ -166,9 +169,9 @@ PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 ro, d3 rd, const HitInfo& h) {
     return c;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(PRT_BLOCK, PRT_RENDER_WAVES) void k_render(DScene S, DCamera C, DRenderParams P,
-                                                                        double* __restrict__ partial, DCounters* ctr) {
+template <bool COUNT, bool FULL>
+__global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WAVES_LEAN)) void k_render(
+    DScene S, DCamera C, DRenderParams P, double* __restrict__ partial, DCounters* ctr) {
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stk = &s_stack[wave][0][lane];
@@ -243,17 +246,16 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_RENDER_WAVES) void k_render(DScene S
                     const DLightTri* lt = S.light_tris + ltri;
                     const d3 ln0 = ld3(lt->n);
                     const d3 ln = dot(lpos - c.pos, ln0) < 0. ? ln0 : -ln0; // SetFaceNormal, Triangle.cpp:89-90
-                    double pdf = 1.0 / lt->area;                             // Triangle.cpp:92, BVH.cpp:91,66
-                    pdf *= lt->area;
-                    pdf /= S.light_area;
+                    const double pdf = lt->pdf;                              // Triangle.cpp:92, BVH.cpp:91,66
                     const d3 emission = ld3(S.materials[lt->material].emission);
                     const d3 wo = world_to_local(-rd, c.f);
                     const d3 lwi = world_to_local(td, c.f);
                     const d3 lln = world_to_local(ln, c.f);
-                    const d3 fr = mat_eval(S, m, lwi, wo, c.uv, rng);
+                    const d3 fr = mat_eval<FULL>(S, m, lwi, wo, c.uv, rng);
                     const double cosT = lwi.z;
                     const double cosTB = dot(lln, -lwi);
-                    const d3 direct = emission * fr * cosT * cosTB / (dist * dist) / pdf; // Camera.cpp:172
+                    // Camera.cpp:172: emission*fr*cosT*cosTB/dist^2/pdf, the scalar factor folded into one division
+                    const d3 direct = (emission * fr) * (cosT * cosTB / ((dist * dist) * pdf));
                     L = L + beta * direct;
                 }
                 state = ST_CLOSEST;
@@ -267,10 +269,10 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_RENDER_WAVES) void k_render(DScene S
                     const ShadeCtx c = make_ctx(S, ro, rd, sh);
                     const DMaterial& m = S.materials[c.material];
                     d3 att, wi;
-                    if (mat_scatter(S, m, rd, c.f, c.uv, rng, att, wi)) {
+                    if (mat_scatter<FULL>(S, m, rd, c.f, c.uv, rng, att, wi)) {
                         depth--; // RayColor(scattered, depth-1): returns 0 when depth-1 < 0
                         if (depth >= 0) {
-                            beta = beta * att / P.rr;
+                            beta = (beta * att) * P.inv_rr;
                             // a zero throughput (Phong bad sample) contributes exactly 0 from here on
                             if (!(beta.x == 0. && beta.y == 0. && beta.z == 0.)) {
                                 ro = c.pos;
@@ -338,9 +340,10 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_RENDER_WAVES) void k_render(DScene S
                 // Ray(ps, normalize(pl-ps)), Interval(0.001, DBL_MAX) (Camera.cpp:143-150).  Any hit nearer
                 // than dist-1e-3 (minus a safety margin) proves occlusion, so traversal may stop there.
                 const d3 to = ro + rd * sh.t;
-                const d3 toL = lpos - to;
+                double dist;
+                const d3 td = normalize_len(lpos - to, dist);
                 n_shadow++;
-                tr.init(S, to, normalize(toL), 0.001, 1.7976931348623157e308, length(toL) - 0.001 - 1e-6);
+                tr.init(S, to, td, 0.001, 1.7976931348623157e308, dist - 0.001 - 1e-6);
             }
         }
         if (__ballot(state != ST_DONE) == 0ULL) break;
@@ -429,10 +432,13 @@ __global__ void k_tonemap(const float* __restrict__ in, size_t n, uint8_t* __res
 // ------------------------------------------------------------------------------------------- launchers
 namespace prt {
 
-int render_blocks_per_cu(bool count) {
+int render_blocks_per_cu(bool count, bool full) {
     int nb = 0;
-    hipError_t e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render<true>, PRT_BLOCK, 0)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render<false>, PRT_BLOCK, 0);
+    hipError_t e;
+    if (count) e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render<true, true>, PRT_BLOCK, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render<true, false>, PRT_BLOCK, 0);
+    else e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render<false, true>, PRT_BLOCK, 0)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render<false, false>, PRT_BLOCK, 0);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
@@ -447,9 +453,12 @@ void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hit
 }
 
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
-                   bool count, unsigned grid, hipStream_t st) {
-    if (count) hipLaunchKernelGGL(k_render<true>, dim3(grid), dim3(PRT_BLOCK), 0, st, S, C, P, d_partial, d_ctr);
-    else hipLaunchKernelGGL(k_render<false>, dim3(grid), dim3(PRT_BLOCK), 0, st, S, C, P, d_partial, d_ctr);
+                   bool count, bool full, unsigned grid, hipStream_t st) {
+    const dim3 g(grid), b(PRT_BLOCK);
+    if (count && full) hipLaunchKernelGGL((k_render<true, true>), g, b, 0, st, S, C, P, d_partial, d_ctr);
+    else if (count) hipLaunchKernelGGL((k_render<true, false>), g, b, 0, st, S, C, P, d_partial, d_ctr);
+    else if (full) hipLaunchKernelGGL((k_render<false, true>), g, b, 0, st, S, C, P, d_partial, d_ctr);
+    else hipLaunchKernelGGL((k_render<false, false>), g, b, 0, st, S, C, P, d_partial, d_ctr);
 }
 
 void launch_finalize(const DCamera& C, const DRenderParams& P, const double* d_partial, double* d64, float* d32,

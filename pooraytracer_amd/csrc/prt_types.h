@@ -17,6 +17,21 @@
 #endif
 #define PRT_BLOCK 256        // threads per workgroup (4 wave64)
 
+#ifndef PRT_NODE16
+#define PRT_NODE16 1 // 1: 32-byte nodes, boxes quantised to a 16-bit scene grid; 0: 64-byte fp32 nodes
+#endif
+
+#if PRT_NODE16
+// 32 bytes = two 16-byte loads per node visit (the texture addresser is the limiter, so bytes and
+// load instructions per visit are what count).  Child boxes are quantised OUTWARD onto a 65536^3
+// grid over the scene bounds: coordinate = grid_origin + q * grid_step.
+struct alignas(32) DNode {
+    uint16_t c0x[2], c0y[2], c0z[2]; // child 0: {lo,hi} x,y,z
+    uint16_t c1x[2], c1y[2], c1z[2]; // child 1
+    int32_t ref0, ref1;              // >=0: inner node index; <0: leaf, ~ref = (first_tri << 3) | (count-1)
+};
+static_assert(sizeof(DNode) == 32, "DNode must be 32 bytes");
+#else
 struct alignas(64) DNode {
     // (lo,hi) pairs per axis so one 16-byte load feeds one axis of one child
     float c0x[2], c0y[2], c0z[2]; // child 0: {lo,hi} x,y,z
@@ -25,6 +40,7 @@ struct alignas(64) DNode {
     int32_t pad[2];
 };
 static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
+#endif
 
 struct alignas(128) DTri {
     double n[3];   // unit geometric normal        (Triangle.cpp:19)
@@ -71,7 +87,8 @@ struct alignas(128) DLightTri {
     double n[3];
     double area;
     int32_t material, prim;
-    double pad[2];
+    double pdf;    // (1/area)*area/total_area evaluated in that order on the host (Triangle.cpp:92, BVH.cpp:91,66)
+    double pad;
 };
 static_assert(sizeof(DLightTri) == 128, "DLightTri must be 128 bytes");
 
@@ -91,6 +108,8 @@ struct DScene {
     uint32_t n_nodes, n_tris;
     float coord_scale;  // largest |coordinate| of any BVH box (fp32, rounded up): bounds the slab-test rounding
     float pad_;
+    float grid_origin[3]; // PRT_NODE16: box coordinate = grid_origin + q * grid_step
+    float grid_step[3];
 };
 
 // camera state after Camera::Initialize (Camera.cpp:75-106), computed on the host
@@ -101,7 +120,7 @@ struct DCamera {
 
 struct DRenderParams {
     int32_t spp, max_depth, sample_lights, chunks;
-    double rr;
+    double rr, inv_rr;
     double background[3];
     uint64_t seed;
     int32_t tile, tiles_x, tiles_y, n_tiles;

@@ -245,6 +245,12 @@ void build_light_tree(const PrtSceneDesc& d, const std::vector<HostTri>& tris, c
     const int32_t top = rb.build(lights, 0, lights.size()); // lights = HittableList(BVHNode(lights)) main.cpp:45
     out.area = rb.nodes[top].area;
     out.root = flatten_light(rb, Obj{-1, top}, out, tris);
+    for (DLightTri& lt : out.tris) { // Triangle::Sample pdf = 1/area; TraverseSample pdf *= area; BVHNode::Sample pdf /= total
+        double pdf = 1.0 / lt.area;
+        pdf *= lt.area;
+        pdf /= out.area;
+        lt.pdf = pdf;
+    }
 }
 
 void setup_camera(const PrtCamera& c, DCamera& out) { // Camera.cpp:75-106
