@@ -36,12 +36,80 @@ WORKLOADS = {
     "veach-mis": ("veach_mis", {}, 3000, 100),
     "bathroom2": ("bathroom", {}, 100, 50),
 }
+# K1 closest-hit microbenchmarks: 2^24 seeded incoherent rays resident in HBM
+RAY_WORKLOADS = {
+    "s0-rays-cornell": ("cornell_box", {}),                          # cache-resident geometry
+    "s4-rays-soup8m": ("triangle_soup", {"n_tris": 8_000_000}),      # HBM-resident: 256 MB nodes + 1 GB triangles
+}
+
+
+def run_ray_microbench(args, torch, api, scenes):
+    """One step = one K1 launch over 2^24 rays (rays and hits stay in HBM)."""
+    import numpy as np
+    fn, kw = RAY_WORKLOADS[args.workload]
+    data = getattr(scenes, fn)(**kw)
+    t0 = time.time()
+    sc = api.Scene(data)
+    build_s = time.time() - t0
+    sc.upload(0)
+    n = 1 << 24
+    lo, hi = data.bounds()
+    rays_np = scenes.random_rays(n, lo, hi, seed=12345)
+    d_r = torch.from_numpy(rays_np.view(np.float64).reshape(-1, 8)).cuda()
+    d_h = torch.zeros((n, 4), dtype=torch.float64, device="cuda")
+    for _ in range(args.warmup):
+        sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr())
+    torch.cuda.synchronize()
+    ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr())
+        ms.append(sc.counters()["kernel_ms"])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr(), count_work=True)
+    torch.cuda.synchronize()
+    cc = sc.counters()
+    npr, tpr = cc["node_fetches"] / n, cc["tri_tests"] / n
+    bpr = bytes_per_ray(npr, tpr)
+    mean_ms = sum(ms) / len(ms)
+    achieved = bpr * n / (mean_ms * 1e-3) / 1e9
+    hits = d_h.cpu().numpy().view(np.dtype([("t", "<f8"), ("a", "<f8"), ("b", "<f8"), ("prim", "<i4"), ("front", "<i4")])).reshape(-1)
+    out = {
+        "metric": "Mrays/s (closest-hit, incoherent rays)", "value": round(n * args.steps / elapsed / 1e6, 2), "unit": "Mrays/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {n} seeded random rays vs {data.n_tris} triangles "
+                               f"({cc['bvh_nodes']} BVH nodes, depth {cc['bvh_depth']}, host build {build_s:.1f} s)",
+                   "hit_fraction": round(float((hits["prim"] >= 0).mean()), 4)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "k_trace_closest",
+                     "kernel_ms": round(mean_ms, 3), "bytes_per_ray": round(bpr, 1), "nodes_per_ray": round(npr, 2),
+                     "tris_per_ray": round(tpr, 2)},
+    }
+    if not args.no_cpu_baseline:
+        import oracle
+        orc = oracle.Oracle(data) if data.n_tris <= 200_000 else None
+        if orc is not None:
+            m = 200_000
+            t0 = time.time()
+            orc.trace_closest(rays_np[:m])
+            dt = time.time() - t0
+            out["cpu_baseline"] = {"value": round(m / dt / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port",
+                                   "sample": f"first {m} rays of the same batch, single thread ({dt:.2f} s)"}
+    print(json.dumps(out), flush=True)
+
+
+
+NODE_BYTES = 32.0   # DNode: both children's boxes on a 16-bit grid + 2 refs (csrc/prt_types.h)
+TRI_BYTES = 128.0   # DTri: fp64 n, D, w, v0, e0, e1
 
 
 def bytes_per_ray(nodes_per_ray, tris_per_ray):
-    """ray in (64 B fp64 o,tmin,d,tmax) + hit out (32 B) + 64 B per BVH node record
-    fetched + 128 B per fp64 triangle record tested (counters from the counting instantiation)."""
-    return 64.0 + 32.0 + 64.0 * nodes_per_ray + 128.0 * tris_per_ray
+    """SURVEY.md §8(d) with this build's record sizes: ray in (64 B fp64 o,tmin,d,tmax) + hit out (32 B)
+    + 32 B per BVH node record fetched + 128 B per fp64 triangle record tested (counters from the
+    counting instantiation of the same kernel)."""
+    return 64.0 + 32.0 + NODE_BYTES * nodes_per_ray + TRI_BYTES * tris_per_ray
 
 
 def cpu_baseline(scene_data, spp, depth, seed, target_s=8.0):
@@ -81,7 +149,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell-box", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cornell-box", choices=sorted(WORKLOADS) + sorted(RAY_WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override spp (0 = the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -108,6 +176,11 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
         dist.barrier()
 
+    if args.workload in RAY_WORKLOADS:
+        if nranks != 1:
+            raise SystemExit("ray microbenchmarks are single-GPU")
+        run_ray_microbench(args, torch, api, scenes)
+        return
     fn, kw, spp, depth = WORKLOADS[args.workload]
     if args.spp > 0:
         spp = args.spp

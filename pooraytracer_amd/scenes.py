@@ -287,7 +287,7 @@ def bathroom(width=1280, height=720, detail=1.0) -> SceneData:
     plastic = b.material(Material("Plastic", _abi.MAT_LAMBERTIAN, kd=(0.2, 0.3, 0.6)))
     k = lambda n: max(2, int(round(n * detail)))  # noqa: E731
     # room: x in [-3,3], y in [0,3], z in [-4,4]; camera near +z looking toward -z
-    b.mesh("floor", floor, *grid_quad((-3, 0, 4), (6, 0, 0), (0, 0, -8), k(48), k(64)))
+    b.mesh("floor", floor, *grid_quad((-3, 0, 4), (6, 0, 0), (0, 0, -8), k(64), k(96)))
     b.mesh("ceiling", wall, *grid_quad((-3, 3, -4), (6, 0, 0), (0, 0, 8), k(24), k(32)))
     b.mesh("wallBack", wall, *grid_quad((-3, 0, -4), (6, 0, 0), (0, 3, 0), k(48), k(24)))
     b.mesh("wallLeft", wall, *grid_quad((-3, 0, 4), (0, 0, -8), (0, 3, 0), k(64), k(24)))
@@ -301,7 +301,7 @@ def bathroom(width=1280, height=720, detail=1.0) -> SceneData:
     b.mesh("absorber", empty, *quad((-1.5, 0.9, -3.97), (1.5, 0.9, -3.97), (1.5, 1.0, -3.97), (-1.5, 1.0, -3.97)))
     # bathtub: displaced tessellated basin (ceramic)
     bump = lambda S, T: -0.45 * np.sin(np.pi * S) * np.sin(np.pi * T) + 0.01 * np.sin(40 * S) * np.sin(40 * T)  # noqa: E731
-    b.mesh("tubTop", ceramic, *grid_quad((0.8, 0.7, -3.6), (2.0, 0, 0), (0, 0, 2.6), k(96), k(128), displace=bump))
+    b.mesh("tubTop", ceramic, *grid_quad((0.8, 0.7, -3.6), (2.0, 0, 0), (0, 0, 2.6), k(128), k(176), displace=bump))
     vb, ub = box((0.8, 0.0, -3.6), (2.8, 0.25, -1.0))
     b.mesh("tubBase", ceramic, vb, ub)
     # sink + cabinet
@@ -311,7 +311,7 @@ def bathroom(width=1280, height=720, detail=1.0) -> SceneData:
     b.mesh("sinkBowl", ceramic, v, uv, n)
     # towel: wavy cloth
     wave = lambda S, T: 0.06 * np.sin(12 * np.pi * S) * (0.3 + T)  # noqa: E731
-    b.mesh("towel", towel, *grid_quad((2.95, 0.9, 0.0), (0, 0, 1.2), (0, 1.2, 0), k(96), k(64), displace=wave))
+    b.mesh("towel", towel, *grid_quad((2.95, 0.9, 0.0), (0, 0, 1.2), (0, 1.2, 0), k(128), k(96), displace=wave))
     # bin (mirror sphere) + plastic bottles
     v, uv, n = icosphere(max(1, int(round(4 * min(1.0, detail) + 0.01))), radius=0.3, center=(-2.3, 0.3, 1.5))
     b.mesh("bin", binm, v, uv, n)
