@@ -143,12 +143,15 @@ typedef struct PrtLightSample {
 typedef struct PrtCounters {
     uint64_t rays_closest;  /* camera + continuation traversals */
     uint64_t rays_shadow;   /* NEE visibility traversals */
-    uint64_t node_fetches;  /* 128-byte BVH node records read (counting runs only) */
+    uint64_t node_fetches;  /* 32-byte BVH node records read (counting runs only) */
     uint64_t tri_tests;     /* 128-byte triangle records tested (counting runs only) */
     uint64_t samples;       /* camera samples started */
     double kernel_ms;       /* hipEvent time of the dominant kernel of the last call */
     uint64_t bvh_nodes;     /* static: nodes in the flattened tree */
     uint64_t bvh_depth;     /* static: max depth */
+    uint64_t inner_rounds;  /* counting runs: wave-level node-visit rounds (64 lanes each) */
+    uint64_t leaf_rounds;   /* counting runs: wave-level leaf rounds */
+    uint64_t refills;       /* counting runs: wave-level shade/refill passes */
 } PrtCounters;
 
 typedef struct PrtScene PrtScene;

@@ -128,6 +128,9 @@ class PrtCounters(C.Structure):
         ("kernel_ms", C.c_double),
         ("bvh_nodes", C.c_uint64),
         ("bvh_depth", C.c_uint64),
+        ("inner_rounds", C.c_uint64),
+        ("leaf_rounds", C.c_uint64),
+        ("refills", C.c_uint64),
     ]
 
 

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -355,6 +356,13 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.sample_lights = p->sample_lights ? 1 : 0;
     P.rr = p->russian_roulette;
     P.inv_rr = 1.0 / p->russian_roulette;
+    // wave scheduling thresholds (developer overrides through the environment for sweeps)
+    P.keep = 16;
+    P.leaf_batch = 32;
+    P.inner_min = 12;
+    if (const char* e = std::getenv("PRT_TUNE_KEEP")) P.keep = std::atoi(e);
+    if (const char* e = std::getenv("PRT_TUNE_LEAF_BATCH")) P.leaf_batch = std::atoi(e);
+    if (const char* e = std::getenv("PRT_TUNE_INNER_MIN")) P.inner_min = std::atoi(e);
     for (int c = 0; c < 3; ++c) P.background[c] = p->background[c];
     P.seed = p->seed;
     int tile = p->tile_size > 0 ? p->tile_size : 32;
@@ -453,6 +461,9 @@ int prt_get_counters(PrtScene* s, PrtCounters* out) {
         c.node_fetches = h.node_fetches;
         c.tri_tests = h.tri_tests;
         c.samples = h.samples;
+        c.inner_rounds = h.inner_rounds;
+        c.leaf_rounds = h.leaf_rounds;
+        c.refills = h.refills;
         c.kernel_ms = ms;
     }
     s->last = c;

@@ -85,6 +85,7 @@ struct HitInfo {
 
 struct WorkCount {
     uint32_t nodes, tris;
+    uint32_t inner_rounds, leaf_rounds; // COUNT builds: wave-level executions of inner_step / leaf_step (lane 0 counts)
 };
 
 // Triangle::Hit + IsInterior (Triangle.cpp:54-83,100-113): same expressions, inclusive interval.
@@ -290,12 +291,15 @@ struct Trav {
     // there until at least PRT_LEAF_BATCH lanes of the wave are parked (or hardly any lane is still
     // descending), and then test their triangles together.
     template <bool COUNT>
-    PRT_DEV void round(const DScene& S, uint32_t* stk, WorkCount& wc) {
+    PRT_DEV void round(const DScene& S, uint32_t* stk, WorkCount& wc, int leaf_batch = PRT_LEAF_BATCH,
+                       int inner_min = PRT_INNER_MIN) {
+        if (COUNT && __ballot(active && cur >= 0) != 0ULL) wc.inner_rounds++;
         if (active && cur >= 0) inner_step<COUNT>(S, stk, wc);
         const bool parked = active && cur < 0;
         const int n_parked = __popcll(__ballot(parked));
         const int n_inner = __popcll(__ballot(active && cur >= 0));
-        if (n_parked >= PRT_LEAF_BATCH || n_inner <= PRT_INNER_MIN) {
+        if (n_parked >= leaf_batch || n_inner <= inner_min) {
+            if (COUNT && n_parked > 0) wc.leaf_rounds++;
             if (parked) leaf_step<COUNT>(S, stk, wc);
         }
     }

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(PRT_BLOCK) void k_trace_closest(DScene S, const Prt
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stk = &s_stack[wave][0][lane];
-    WorkCount wc{0, 0};
+    WorkCount wc{0, 0, 0, 0};
     uint32_t nrays = 0;
     Trav tr;
     tr.init(S, mk3(0, 0, 0), mk3(0, 0, 1), 0.0, 0.0, 0.0);
@@ -153,6 +153,7 @@ struct ShadeCtx {
     d2 uv;
     int32_t material;
 };
+template <bool FULL>
 PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 ro, d3 rd, const HitInfo& h) {
     ShadeCtx c;
     const DTriShade* sh = S.shade + h.tri;
@@ -162,9 +163,13 @@ PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 ro, d3 rd, const HitInfo& h) {
     c.f.n = front ? gn : -gn;
     c.f.t = ld3(sh->tangent);
     c.pos = ro + rd * h.t;
-    const double w0 = 1. - h.alpha - h.beta;
-    c.uv.x = w0 * sh->uv0[0] + h.alpha * sh->uv1[0] + h.beta * sh->uv2[0];
-    c.uv.y = w0 * sh->uv0[1] + h.alpha * sh->uv1[1] + h.beta * sh->uv2[1];
+    if (FULL) { // texture coordinates are only read by image-textured materials
+        const double w0 = 1. - h.alpha - h.beta;
+        c.uv.x = w0 * sh->uv0[0] + h.alpha * sh->uv1[0] + h.beta * sh->uv2[0];
+        c.uv.y = w0 * sh->uv0[1] + h.alpha * sh->uv1[1] + h.beta * sh->uv2[1];
+    } else {
+        c.uv.x = c.uv.y = 0.0;
+    }
     c.material = sh->material;
     return c;
 }
@@ -175,56 +180,77 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stk = &s_stack[wave][0][lane];
+    d3 pst_[3]; // acc, L (radiance of the current sample), beta (path throughput)
+#define PST_LD(k) (pst_[(k) / 3])
+#define PST_ST(k, v) (pst_[(k) / 3] = (v))
+#define S_ACC 0
+#define S_L 3
+#define S_BETA 6
 
-    WorkCount wc{0, 0};
-    uint32_t n_closest = 0, n_shadow = 0, n_samples = 0;
+    WorkCount wc{0, 0, 0, 0};
+    uint32_t n_closest = 0, n_shadow = 0, n_samples = 0, n_refills = 0;
 
     int state = ST_FETCH;
     uint64_t item = 0;
     int px = 0, py = 0, s = 0, s_end = 0, depth = 0;
     bool first = true, prev_skip = false;
-    d3 acc = mk3(0, 0, 0);  // sum over this item's samples of colour * (1/spp)
-    d3 L = mk3(0, 0, 0);    // radiance of the current sample
-    d3 beta = mk3(1, 1, 1); // path throughput
-    d3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 1); // the ray whose closest hit is being shaded
-    HitInfo sh;                               // its hit (valid in ST_SHADOW)
-    sh.t = 0; sh.alpha = 0; sh.beta = 0; sh.tri = -1;
-    d3 lpos = mk3(0, 0, 0);                   // sampled light point (valid in ST_SHADOW)
+    PST_ST(S_ACC, mk3(0, 0, 0));  // sum over this item's samples of colour * (1/spp)
+    PST_ST(S_L, mk3(0, 0, 0));    // radiance of the current sample
+    PST_ST(S_BETA, mk3(1, 1, 1)); // path throughput
+    // Across a continuation traversal the ray lives in tr.o / tr.d only.  Across a shadow traversal
+    // tr.o is the shading point itself, so only the incoming direction, the hit's barycentrics and
+    // the light pick need to be kept.
+    d3 rd = mk3(0, 0, 1);        // incoming direction at the shading point (valid in ST_SHADOW)
+    double sh_alpha = 0, sh_beta = 0;
+    int32_t sh_tri = -1;
+    double ldist = 0;            // distance to the sampled light point (valid in ST_SHADOW)
     int32_t ltri = 0;
     Rng rng;
     rng.s = 0;
     const double inv_spp = 1.0 / P.spp; // pixelSamplesScale, Camera.cpp:83
     Trav tr;
-    tr.init(S, ro, rd, 0.0, 0.0, 0.0);
+    tr.init(S, mk3(0, 0, 0), rd, 0.0, 0.0, 0.0);
     tr.active = false;
 
     for (;;) {
+        if (COUNT) n_refills++;
         if (!tr.active) {
             // ---------------- a traversal has just finished on this lane: consume its result
             bool end_sample = false, do_scatter = false;
+            d3 next_o = mk3(0, 0, 0), next_d = mk3(0, 0, 1); // the ray to trace next when state ends up ST_CLOSEST
+            d3 pos = tr.o;                 // shading point (ST_SHADOW: the shadow ray's origin)
+            d3 shadow_dir = mk3(0, 0, 1);
+            HitInfo sh;
             if (state == ST_CLOSEST) {
                 const HitInfo h = tr.hit;
                 if (h.tri < 0) {
                     // miss: background for the camera ray (Camera.cpp:127); with bSampleLights a bounce miss adds 0 (:187)
-                    if (first || !P.sample_lights) L = L + beta * ld3(P.background);
+                    if (first || !P.sample_lights) PST_ST(S_L, PST_LD(S_L) + PST_LD(S_BETA) * ld3(P.background));
                     end_sample = true;
                 } else {
                     const DMaterial& m = S.materials[S.shade[h.tri].material];
                     if (m.has_emission) {
                         // Camera.cpp:129-132; via a bounce only after SkipLightSampling materials (:191-195)
-                        if (first || !P.sample_lights || prev_skip) L = L + beta * ld3(m.emission);
+                        if (first || !P.sample_lights || prev_skip) PST_ST(S_L, PST_LD(S_L) + PST_LD(S_BETA) * ld3(m.emission));
                         end_sample = true;
                     } else {
-                        sh = h;
+                        rd = tr.d;
+                        sh_alpha = h.alpha;
+                        sh_beta = h.beta;
+                        sh_tri = h.tri;
+                        pos = tr.o + tr.d * h.t; // record.position = ray(t)
                         do_scatter = true;
                         if (P.sample_lights && S.n_lights > 0 && !m.skip_light_sampling) {
                             // next-event estimation, Camera.cpp:137-155: pick the light point now (4 draws)
-                            const ShadeCtx c = make_ctx(S, ro, rd, sh);
-                            const LightPick lp = sample_lights(S, c.pos, rng);
-                            const d3 ldir = normalize(lp.pos - c.pos);
-                            if (dot(c.f.n, ldir) > 0.0 && lp.front) {
-                                lpos = lp.pos;
+                            const d3 gn = ld3(S.tris[h.tri].n);
+                            const d3 fn = dot(rd, gn) < 0. ? gn : -gn;
+                            const LightPick lp = sample_lights(S, pos, rng);
+                            double dist;
+                            const d3 ldir = normalize_len(lp.pos - pos, dist);
+                            if (dot(fn, ldir) > 0.0 && lp.front) {
                                 ltri = lp.tri;
+                                ldist = dist;
+                                shadow_dir = ldir;
                                 state = ST_SHADOW; // trace the shadow ray, then scatter
                                 do_scatter = false;
                             }
@@ -233,19 +259,24 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
                 }
             } else if (state == ST_SHADOW) {
                 // ---- shadow ray returned: visibility = closest hit no nearer than dist - 1e-3 (Camera.cpp:152-155)
-                const ShadeCtx c = make_ctx(S, ro, rd, sh);
                 const d3 to = tr.o, td = tr.d;
-                const double dist = length(lpos - to);
+                const double dist = ldist;
                 bool visible = true; // an escaping shadow ray counts as unoccluded
                 if (tr.hit.tri >= 0) {
                     const d3 pn = to + td * tr.hit.t;
                     visible = (dist - length(to - pn)) < 0.001;
                 }
                 if (visible) {
+                    sh.t = 0.0;
+                    sh.alpha = sh_alpha;
+                    sh.beta = sh_beta;
+                    sh.tri = sh_tri;
+                    const ShadeCtx c = make_ctx<FULL>(S, to, rd, sh);
                     const DMaterial& m = S.materials[c.material];
                     const DLightTri* lt = S.light_tris + ltri;
                     const d3 ln0 = ld3(lt->n);
-                    const d3 ln = dot(lpos - c.pos, ln0) < 0. ? ln0 : -ln0; // SetFaceNormal, Triangle.cpp:89-90
+                    // SetFaceNormal(Ray(origin, p - origin), normal) (Triangle.cpp:89-90); p - origin = td * dist
+                    const d3 ln = dot(td, ln0) < 0. ? ln0 : -ln0;
                     const double pdf = lt->pdf;                              // Triangle.cpp:92, BVH.cpp:91,66
                     const d3 emission = ld3(S.materials[lt->material].emission);
                     const d3 wo = world_to_local(-rd, c.f);
@@ -256,7 +287,7 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
                     const double cosTB = dot(lln, -lwi);
                     // Camera.cpp:172: emission*fr*cosT*cosTB/dist^2/pdf, the scalar factor folded into one division
                     const d3 direct = (emission * fr) * (cosT * cosTB / ((dist * dist) * pdf));
-                    L = L + beta * direct;
+                    PST_ST(S_L, PST_LD(S_L) + PST_LD(S_BETA) * direct);
                 }
                 state = ST_CLOSEST;
                 do_scatter = true;
@@ -266,17 +297,22 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
                 // ---- Russian roulette + Scatter, Camera.cpp:176-202
                 end_sample = true;
                 if (rng.next() < P.rr) {
-                    const ShadeCtx c = make_ctx(S, ro, rd, sh);
+                    sh.t = 0.0;
+                    sh.alpha = sh_alpha;
+                    sh.beta = sh_beta;
+                    sh.tri = sh_tri;
+                    const ShadeCtx c = make_ctx<FULL>(S, pos, rd, sh);
                     const DMaterial& m = S.materials[c.material];
                     d3 att, wi;
                     if (mat_scatter<FULL>(S, m, rd, c.f, c.uv, rng, att, wi)) {
                         depth--; // RayColor(scattered, depth-1): returns 0 when depth-1 < 0
                         if (depth >= 0) {
-                            beta = (beta * att) * P.inv_rr;
+                            const d3 beta = (PST_LD(S_BETA) * att) * P.inv_rr;
+                            PST_ST(S_BETA, beta);
                             // a zero throughput (Phong bad sample) contributes exactly 0 from here on
                             if (!(beta.x == 0. && beta.y == 0. && beta.z == 0.)) {
-                                ro = c.pos;
-                                rd = wi;
+                                next_o = pos;
+                                next_d = wi;
                                 prev_skip = m.skip_light_sampling != 0;
                                 first = false;
                                 end_sample = false;
@@ -286,7 +322,8 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
                 }
             }
             if (end_sample) {
-                acc = acc + L * inv_spp; // colorAttachment[m] += RayColor(...) * pixelSamplesScale (Camera.cpp:56)
+                const d3 acc = PST_LD(S_ACC) + PST_LD(S_L) * inv_spp; // colorAttachment[m] += RayColor(...) * pixelSamplesScale (Camera.cpp:56)
+                PST_ST(S_ACC, acc);
                 s++;
                 if (s < s_end) state = ST_NEW_SAMPLE;
                 else {
@@ -309,7 +346,7 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
                     if (owned_to_pixel(P, C, oi, px, py)) {
                         s = (int)(((int64_t)chunk * P.spp) / P.chunks);
                         s_end = (int)(((int64_t)(chunk + 1) * P.spp) / P.chunks);
-                        acc = mk3(0, 0, 0);
+                        PST_ST(S_ACC, mk3(0, 0, 0));
                         if (s < s_end) state = ST_NEW_SAMPLE;
                         else {
                             double* o = partial + item * 3;
@@ -322,10 +359,10 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
                 // per-sample stream keyed (seed, j*W+i, s); Camera::GetRay (Camera.cpp:108-117): pixel centre, no jitter
                 rng.seed(P.seed, (uint64_t)py * (uint64_t)C.width + (uint64_t)px, (uint64_t)s);
                 const d3 ps = ld3(C.pixel00) + ((double)px) * ld3(C.du) + ((double)py) * ld3(C.dv);
-                ro = ld3(C.center);
-                rd = ps - ro;
-                L = mk3(0, 0, 0);
-                beta = mk3(1, 1, 1);
+                next_o = ld3(C.center);
+                next_d = ps - next_o;
+                PST_ST(S_L, mk3(0, 0, 0));
+                PST_ST(S_BETA, mk3(1, 1, 1));
                 depth = P.max_depth;
                 first = true;
                 prev_skip = false;
@@ -335,23 +372,20 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
             // ---------------- start the traversal this lane needs next
             if (state == ST_CLOSEST) {
                 n_closest++;
-                tr.init(S, ro, rd, 0.0001, PRT_INF, -PRT_INF); // Camera.cpp:125
+                tr.init(S, next_o, next_d, 0.0001, PRT_INF, -PRT_INF); // Camera.cpp:125
             } else if (state == ST_SHADOW) {
                 // Ray(ps, normalize(pl-ps)), Interval(0.001, DBL_MAX) (Camera.cpp:143-150).  Any hit nearer
                 // than dist-1e-3 (minus a safety margin) proves occlusion, so traversal may stop there.
-                const d3 to = ro + rd * sh.t;
-                double dist;
-                const d3 td = normalize_len(lpos - to, dist);
                 n_shadow++;
-                tr.init(S, to, td, 0.001, 1.7976931348623157e308, dist - 0.001 - 1e-6);
+                tr.init(S, pos, shadow_dir, 0.001, 1.7976931348623157e308, ldist - 0.001 - 1e-6);
             }
         }
         if (__ballot(state != ST_DONE) == 0ULL) break;
 
         // ---------------- traversal steps until enough lanes have finished to be worth refilling
         do {
-            tr.round<COUNT>(S, stk, wc);
-        } while (wave_count(tr.active) > PRT_K3_KEEP);
+            tr.round<COUNT>(S, stk, wc, P.leaf_batch, P.inner_min);
+        } while (wave_count(tr.active) > P.keep);
     }
 
     unsigned long long a = wave_sum((unsigned long long)n_closest);
@@ -366,6 +400,9 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
         if (COUNT) {
             atomicAdd(&ctr->node_fetches, d);
             atomicAdd(&ctr->tri_tests, e);
+            atomicAdd(&ctr->inner_rounds, (unsigned long long)wc.inner_rounds);
+            atomicAdd(&ctr->leaf_rounds, (unsigned long long)wc.leaf_rounds);
+            atomicAdd(&ctr->refills, (unsigned long long)n_refills);
         }
     }
 }

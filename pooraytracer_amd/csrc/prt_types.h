@@ -125,6 +125,7 @@ struct DRenderParams {
     uint64_t seed;
     int32_t tile, tiles_x, tiles_y, n_tiles;
     int32_t rank, nranks, owned_tiles, pad;
+    int32_t keep, leaf_batch, inner_min, pad2; // wave scheduling thresholds of K3 (see prt_kernels.hip)
     uint64_t items_per_chunk; // owned_tiles * tile * tile
     uint64_t n_items;         // items_per_chunk * chunks
 };
@@ -133,4 +134,5 @@ struct DRenderParams {
 struct DCounters {
     unsigned long long next_item;
     unsigned long long rays_closest, rays_shadow, node_fetches, tri_tests, samples;
+    unsigned long long inner_rounds, leaf_rounds, refills; // COUNT builds: wave-level scheduling statistics
 };

@@ -23,9 +23,11 @@ def main():
     res.update(render_s=round(dt, 4), kernel_ms=round(c["kernel_ms"], 2), mrays=round(rays / dt / 1e6, 1), rays_per_sample=round(rays / c["samples"], 2),
                mean=[round(float(x), 5) for x in out.mean(dim=(0, 1)).tolist()])
     if os.environ.get("QB_COUNT"):
-        sc.render_device(None, out.data_ptr(), spp=2, max_depth=depth, count_work=True); torch.cuda.synchronize()
+        sc.render_device(None, out.data_ptr(), spp=spp, max_depth=depth, count_work=True); torch.cuda.synchronize()
         c = sc.counters(); r = c["rays_closest"] + c["rays_shadow"]
-        res.update(nodes_per_ray=round(c["node_fetches"] / r, 2), tris_per_ray=round(c["tri_tests"] / r, 2))
+        res.update(nodes_per_ray=round(c["node_fetches"] / r, 2), tris_per_ray=round(c["tri_tests"] / r, 2),
+                   inner_util=round(c["node_fetches"] / max(1, 64 * c["inner_rounds"]), 3), leaf_rounds_per_ray=round(64 * c["leaf_rounds"] / r, 2),
+                   inner_rounds_x64_per_ray=round(64 * c["inner_rounds"] / r, 2), refills_x64_per_ray=round(64 * c["refills"] / r, 2))
     # K1 microbench: incoherent rays
     lo, hi = data.bounds()
     n = 1 << 22
