@@ -35,22 +35,25 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
 
 HOST_LIB = os.path.join(HERE, "libpooraytracer_host.so")
 HOST_EXE = os.path.join(HERE, "render_scene")
+MAIN_EXE = os.path.join(HERE, "pooraytracer_main")
 ROOT = os.path.dirname(HERE)
 
 
 def build_host_example(force=False):
     """g++ build of the C++ host API (include/pooraytracer/*.h over the C ABI) and the main.cpp-style driver."""
-    src = os.path.join(HERE, "host", "host_api.cpp")
+    srcs = [os.path.join(HERE, "host", "host_api.cpp"), os.path.join(HERE, "host", "model.cpp")]
     exe_src = os.path.join(ROOT, "examples", "render_scene.cpp")
+    main_src = os.path.join(ROOT, "examples", "pooraytracer_main.cpp")
     inc = os.path.join(ROOT, "include")
-    deps = [src, exe_src] + [os.path.join(inc, "pooraytracer", f) for f in os.listdir(os.path.join(inc, "pooraytracer"))]
-    fresh = all(os.path.exists(x) and os.path.getmtime(x) >= max(os.path.getmtime(d) for d in deps) for x in (HOST_LIB, HOST_EXE))
+    deps = srcs + [exe_src, main_src, os.path.join(inc, "prt.h")] + [os.path.join(inc, "pooraytracer", f) for f in os.listdir(os.path.join(inc, "pooraytracer"))]
+    fresh = all(os.path.exists(x) and os.path.getmtime(x) >= max(os.path.getmtime(d) for d in deps) for x in (HOST_LIB, HOST_EXE, MAIN_EXE))
     if fresh and not force:
         return HOST_EXE
     build()
     common = ["-O2", "-std=c++17", "-Wall", "-I", inc, "-L", HERE, "-Wl,-rpath,$ORIGIN"]
-    subprocess.check_call(["g++", "-shared", "-fPIC"] + common + ["-o", HOST_LIB, src, "-lprt_hip"])
+    subprocess.check_call(["g++", "-shared", "-fPIC"] + common + ["-o", HOST_LIB] + srcs + ["-lprt_hip"])
     subprocess.check_call(["g++"] + common + ["-o", HOST_EXE, exe_src, "-lpooraytracer_host", "-lprt_hip"])
+    subprocess.check_call(["g++"] + common + ["-o", MAIN_EXE, main_src, "-lpooraytracer_host", "-lprt_hip"])
     return HOST_EXE
 
 

@@ -417,3 +417,65 @@ def dump_scene(scene: SceneData, path: str):
             rec = np.concatenate([scene.vertices[a:b].reshape(b - a, 9), scene.normals[a:b].reshape(b - a, 9),
                                   scene.texcoords[a:b].reshape(b - a, 6)], axis=1)
             f.write(np.ascontiguousarray(rec, dtype=np.float64).tobytes())
+
+
+def apply_loader_uv_fixup(scene: SceneData) -> SceneData:
+    """The reference's OBJ loader replaces the texcoords of a triangle whose three UVs are not pairwise
+    distinct by (0,0),(1,0),(1,1) (Source/Model.cpp:170-175).  Returns a copy with that rule applied,
+    i.e. the scene as the C++ Model class hands it to the renderer."""
+    import copy
+    out = copy.copy(scene)
+    tc = scene.texcoords.copy()
+    eq = lambda a, b: (tc[:, a] == tc[:, b]).all(axis=1)  # noqa: E731
+    bad = eq(0, 1) | eq(1, 2) | eq(0, 2)
+    tc[bad] = np.array([[0.0, 0.0], [1.0, 0.0], [1.0, 1.0]])
+    out.texcoords = tc
+    return out
+
+
+def export_obj(scene: SceneData, resources_dir: str, lights_only_table_names=True):
+    """Write <resources_dir>/<name>/<name>.obj, .mtl, .xml (+ P6 .ppm textures) in the layout the
+    reference reads (main.cpp:17-33).  Numbers are written with 17 significant
+    digits so they round-trip exactly."""
+    import os
+    d = os.path.join(resources_dir, scene.name)
+    os.makedirs(d, exist_ok=True)
+    fmt = lambda xs: " ".join(repr(float(x)) for x in xs)  # noqa: E731
+    with open(os.path.join(d, scene.name + ".mtl"), "w") as f:
+        for m in scene.materials:
+            f.write(f"newmtl {m.name}\nKd {fmt(m.kd)}\nKs {fmt(m.ks)}\nNs {repr(float(m.ns))}\n")
+            if m.texture >= 0:
+                f.write(f"map_Kd tex{m.texture}.ppm\n")
+            f.write("\n")
+    for i, t in enumerate(scene.textures):
+        t = np.ascontiguousarray(t, dtype=np.uint8)
+        with open(os.path.join(d, f"tex{i}.ppm"), "wb") as f:
+            f.write(f"P6\n{t.shape[1]} {t.shape[0]}\n255\n".encode())
+            f.write(t.tobytes())
+    with open(os.path.join(d, scene.name + ".obj"), "w") as f:
+        f.write(f"mtllib {scene.name}.mtl\n")
+        n = 0
+        for i, mat in enumerate(scene.mesh_material):
+            a, b = int(scene.mesh_first_tri[i]), int(scene.mesh_first_tri[i + 1])
+            f.write(f"g {scene.mesh_names[i]}\nusemtl {scene.materials[int(mat)].name}\n")
+            lines = []
+            for t in range(a, b):
+                for k in range(3):
+                    lines.append("v " + fmt(scene.vertices[t, k]))
+                    lines.append("vt " + fmt(scene.texcoords[t, k]))
+                    lines.append("vn " + fmt(scene.normals[t, k]))
+                j = n * 3
+                lines.append(f"f {j + 1}/{j + 1}/{j + 1} {j + 2}/{j + 2}/{j + 2} {j + 3}/{j + 3}/{j + 3}")
+                n += 1
+            f.write("\n".join(lines) + "\n")
+    cam = scene.camera
+    with open(os.path.join(d, scene.name + ".xml"), "w") as f:
+        f.write('<?xml version="1.0" encoding="utf-8"?>\n')
+        f.write(f'<camera type="perspective" width="{cam.width}" height="{cam.height}" fovy="{repr(float(cam.fovy))}">\n')
+        f.write('  <eye x="%r" y="%r" z="%r"/>\n' % tuple(float(x) for x in cam.eye))
+        f.write('  <lookat x="%r" y="%r" z="%r"/>\n' % tuple(float(x) for x in cam.look_at))
+        f.write('  <up x="%r" y="%r" z="%r"/>\n</camera>\n' % tuple(float(x) for x in cam.up))
+        for m in scene.materials:
+            if m.type == _abi.MAT_DIFFUSE_LIGHT:
+                f.write('<light mtlname="%s" radiance="%r,%r,%r"/>\n' % ((m.name,) + tuple(float(x) for x in m.emission)))
+    return d

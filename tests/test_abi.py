@@ -77,3 +77,18 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "oracle.h" not in txt, f
+
+
+def test_cpp_driver_fails_loudly_without_gpu(tmp_path):
+    """The C++ host path has no CPU fallback either: on a machine without a HIP device the
+    main.cpp-style driver must exit non-zero with the library's error, after loading the scene."""
+    from pooraytracer_amd import build
+    build.build_host_example()
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present")
+    data = scenes.tiny_scene()
+    res = str(tmp_path / "res")
+    scenes.export_obj(data, res)
+    r = subprocess.run([build.MAIN_EXE, res, data.name, "1", "1", str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "no HIP device" in r.stderr or "prt_scene_upload" in r.stderr
