@@ -169,11 +169,19 @@ def main():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if rank == 0:
         build.build()  # no-op when libprt_hip.so is fresh
+    # PRT_BENCH_REHEARSAL=1: exercise the N>1 path on a ONE-GPU box — every rank shares cuda:0 and the
+    # reduce goes through gloo on host copies (RCCL refuses two ranks on one device).  Not a measurement.
+    rehearsal = os.environ.get("PRT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if nranks > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=nranks,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=nranks)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=nranks,
+                                    device_id=torch.device("cuda", local_rank))
         dist.barrier()
 
     if args.workload in RAY_WORKLOADS:
@@ -194,7 +202,12 @@ def main():
 
     def step():
         sc.render_device(None, fb.data_ptr(), stream=stream, **render_kw)
-        distributed.reduce_framebuffer(fb, dst=0)
+        if rehearsal and nranks > 1:
+            host = fb.cpu()
+            distributed.reduce_framebuffer(host, dst=0)
+            fb.copy_(host)
+        else:
+            distributed.reduce_framebuffer(fb, dst=0)
 
     def fence():
         if nranks > 1:
@@ -218,13 +231,20 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if nranks > 1:
-        t = torch.tensor([elapsed, float(rays), float(samples)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, float(rays), float(samples)], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
         rays, samples = int(t[1]), int(t[2])
 
+    if rank == 0 and nranks > 1 and os.environ.get("PRT_BENCH_VERIFY") == "1":
+        # outside the timed region: the reduced framebuffer must equal a single-rank render bit for bit
+        assembled = fb.clone()
+        sc.render_device(None, fb.data_ptr(), stream=stream, **dict(render_kw, rank=0, nranks=1))
+        torch.cuda.synchronize()
+        print("[bench] N=%d assembled image %s the single-rank image" %
+              (nranks, "EQUALS" if torch.equal(assembled, fb) else "DIFFERS FROM"), file=sys.stderr, flush=True)
     if rank == 0:
         # counting instantiation (outside the timed region): mean node fetches / triangle tests per ray
         sc.render_device(None, fb.data_ptr(), count_work=True, stream=stream,
@@ -250,7 +270,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
             "config": {
                 "workload": f"{args.workload} (synthetic stand-in, {data.n_tris} tris) {cam.width}x{cam.height} "
                             f"spp={spp} depth={depth} rr=0.8 bSampleLights seed={seed}",
