@@ -379,10 +379,15 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     const int bpc = s->blocks_per_cu[count ? 1 : 0];
     const uint64_t lanes = (uint64_t)s->n_cu * bpc * PRT_BLOCK;
     int chunks = p->sample_chunks;
-    if (chunks <= 0) { // enough items that the dynamic queue levels the tail: >= 8 items per resident lane
+    if (chunks <= 0) {
+        // Work item = (pixel, chunk of samples).  Two constraints: enough items that the dynamic queue can
+        // level the load (>= 8 per resident lane), and items short enough (~32 samples) that the tail —
+        // lanes that ran out of items while their wave-mates finish their last one — stays ~1 % of a frame.
         chunks = 1;
         if (P.items_per_chunk) chunks = (int)std::min<uint64_t>(64, (8 * lanes + P.items_per_chunk - 1) / P.items_per_chunk);
+        chunks = std::max(chunks, std::min(64, (p->spp + 31) / 32));
     }
+    if (const char* e = std::getenv("PRT_TUNE_CHUNKS")) chunks = std::atoi(e);
     chunks = std::max(1, std::min(chunks, p->spp));
     P.chunks = chunks;
     P.n_items = P.items_per_chunk * (uint64_t)chunks;
