@@ -378,17 +378,44 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     const bool count = count_work != 0;
     const int bpc = s->blocks_per_cu[count ? 1 : 0];
     const uint64_t lanes = (uint64_t)s->n_cu * bpc * PRT_BLOCK;
-    int chunks = p->sample_chunks;
-    if (chunks <= 0) {
-        // Work item = (pixel, chunk of samples).  Two constraints: enough items that the dynamic queue can
-        // level the load (>= 8 per resident lane), and items short enough (~32 samples) that the tail —
-        // lanes that ran out of items while their wave-mates finish their last one — stays ~1 % of a frame.
-        chunks = 1;
-        if (P.items_per_chunk) chunks = (int)std::min<uint64_t>(64, (8 * lanes + P.items_per_chunk - 1) / P.items_per_chunk);
-        chunks = std::max(chunks, std::min(64, (p->spp + 31) / 32));
+    // Work item = (pixel, chunk of samples), dealt chunk-major from one global counter.
+    //  * explicit sample_chunks: that many equal chunks;
+    //  * auto: a guided schedule — equal "body" chunks (enough items that the dynamic queue levels the
+    //    load: >= 8 per resident lane, ~32-64 samples each) followed by a tail of halving chunks down to
+    //    4 samples, so the lanes that run out of items last are only a few rays behind.  Item fetches
+    //    (returning atomics, microseconds each) stay as rare as with the body size alone.
+    std::vector<int> sizes;
+    const int spp = p->spp;
+    int want = p->sample_chunks;
+    if (const char* e = std::getenv("PRT_TUNE_CHUNKS")) want = std::atoi(e);
+    if (want > 0) {
+        want = std::min(want, std::min(spp, PRT_MAX_CHUNKS));
+        for (int c = 0; c < want; ++c) sizes.push_back((int)(((int64_t)(c + 1) * spp) / want - ((int64_t)c * spp) / want));
+    } else {
+        int body_chunks = 1;
+        if (P.items_per_chunk) body_chunks = (int)std::min<uint64_t>(32, (8 * lanes + P.items_per_chunk - 1) / P.items_per_chunk);
+        body_chunks = std::max(body_chunks, std::min(32, (spp + 47) / 48));
+        int body = std::max(1, spp / std::max(1, body_chunks));
+        int left = spp;
+        // tail: 2 x body/2, 2 x body/4, ... , 4 x 4 samples (only when spp is large enough to matter)
+        std::vector<int> tail;
+        if (spp >= 64) {
+            for (int sz = 4, n = 4; sz < body && (int)tail.size() < 16; sz *= 2, n = 2)
+                for (int k = 0; k < n; ++k) tail.push_back(sz);
+        }
+        int tail_sum = 0;
+        for (int t : tail) tail_sum += t;
+        while (!tail.empty() && tail_sum > spp / 3) { tail_sum -= tail.back(); tail.pop_back(); }
+        left -= tail_sum;
+        const int nb = std::max(1, std::min(PRT_MAX_CHUNKS - (int)tail.size(), (left + body - 1) / body));
+        for (int c = 0; c < nb; ++c) sizes.push_back((int)(((int64_t)(c + 1) * left) / nb - ((int64_t)c * left) / nb));
+        for (auto it = tail.rbegin(); it != tail.rend(); ++it) sizes.push_back(*it); // largest tail chunks first
     }
-    if (const char* e = std::getenv("PRT_TUNE_CHUNKS")) chunks = std::atoi(e);
-    chunks = std::max(1, std::min(chunks, p->spp));
+    sizes.erase(std::remove(sizes.begin(), sizes.end(), 0), sizes.end());
+    if (sizes.empty()) sizes.push_back(spp);
+    int chunks = (int)sizes.size();
+    P.chunk_begin[0] = 0;
+    for (int c = 0; c < chunks; ++c) P.chunk_begin[c + 1] = P.chunk_begin[c] + sizes[c];
     P.chunks = chunks;
     P.n_items = P.items_per_chunk * (uint64_t)chunks;
 

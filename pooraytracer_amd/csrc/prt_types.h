@@ -16,6 +16,7 @@
 #define PRT_LEAF_MAX 4       // triangles per BVH leaf (leaf ref stores count-1 in 3 bits)
 #endif
 #define PRT_BLOCK 256        // threads per workgroup (4 wave64)
+#define PRT_MAX_CHUNKS 64    // sample chunks per pixel (work items per pixel)
 
 #ifndef PRT_NODE16
 #define PRT_NODE16 1 // 1: 32-byte nodes, boxes quantised to a 16-bit scene grid; 0: 64-byte fp32 nodes
@@ -128,6 +129,7 @@ struct DRenderParams {
     int32_t keep, leaf_batch, inner_min, pad2; // wave scheduling thresholds of K3 (see prt_kernels.hip)
     uint64_t items_per_chunk; // owned_tiles * tile * tile
     uint64_t n_items;         // items_per_chunk * chunks
+    int32_t chunk_begin[PRT_MAX_CHUNKS + 1]; // chunk c covers samples [chunk_begin[c], chunk_begin[c+1])
 };
 
 // device-side counters, zeroed before each call
