@@ -221,3 +221,67 @@ def test_full_size_properties(gpu):
     # a row band rendered by the oracle matches
     cpu, _ = oracle.Oracle(data).render(spp=2, max_depth=20, rows=(500, 504), nthreads=4)
     compare_images(a[500:504], cpu[500:504], max_bad_frac=2e-3)
+
+
+def test_closest_hit_optimality_large_soup(gpu):
+    """Size-independent properties of K1 on a BVH far beyond the oracle's reach (2M random triangles,
+    deep tree): (1) every reported hit lies on its triangle: o + t d == v0 + alpha e0 + beta e1 with
+    valid barycentrics; (2) closest-ness: re-tracing with tmax just below t finds nothing on the same
+    primitive and anything it finds is strictly nearer than t is impossible -> must be a miss;
+    (3) a brute-force check of a ray subset against ALL triangles with the reference formulas."""
+    data = scenes.triangle_soup(2_000_000, seed=9, with_light=False)
+    sc = api.Scene(data).upload(gpu)
+    assert sc.counters()["bvh_depth"] <= 30
+    lo, hi = data.bounds()
+    rays = scenes.random_rays(200_000, lo, hi, seed=21)
+    h = sc.trace_closest(rays)
+    hit = h["prim"] >= 0
+    assert hit.mean() > 0.5
+    v = data.vertices[h["prim"][hit]]
+    p_ray = rays["o"][hit] + rays["d"][hit] * h["t"][hit, None]
+    p_tri = v[:, 0] + h["alpha"][hit, None] * (v[:, 1] - v[:, 0]) + h["beta"][hit, None] * (v[:, 2] - v[:, 0])
+    assert np.abs(p_ray - p_tri).max() < 1e-10
+    assert (h["alpha"][hit] >= 0).all() and (h["beta"][hit] >= 0).all() and (h["alpha"][hit] + h["beta"][hit] <= 1 + 1e-15).all()
+    assert (h["t"][hit] >= 1e-4).all()
+    # closest-ness: nothing in [tmin, t*(1-1e-9)]
+    r2 = rays[hit].copy()
+    r2["tmax"] = h["t"][hit] * (1 - 1e-9)
+    assert (sc.trace_closest(r2)["prim"] == -1).all()
+    # brute force for a few rays (reference formulas, Triangle.cpp:54-83)
+    V = data.vertices
+    e0, e1 = V[:, 1] - V[:, 0], V[:, 2] - V[:, 0]
+    n = np.cross(e0, e1)
+    nn = n / np.linalg.norm(n, axis=1, keepdims=True)
+    D = (nn * V[:, 0]).sum(1)
+    w = n / (n * n).sum(1, keepdims=True)
+    for i in range(0, 200_000, 20_000):
+        oo, dd = rays["o"][i], rays["d"][i]
+        den = nn @ dd
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (D - nn @ oo) / den
+        v0p = oo + dd * t[:, None] - V[:, 0]
+        al = (w * np.cross(v0p, e1)).sum(1)
+        be = (w * np.cross(e0, v0p)).sum(1)
+        ok = (np.abs(den) >= 1e-8) & (t >= 1e-4) & (al >= 0) & (be >= 0) & (al + be <= 1)
+        if ok.any():
+            tt = np.where(ok, t, np.inf)
+            assert h["prim"][i] == int(np.argmin(tt)) or h["t"][i] == tt.min()
+            assert abs(h["t"][i] - tt.min()) <= 1e-12 * max(1.0, tt.min())
+        else:
+            assert h["prim"][i] == -1
+
+
+@pytest.mark.parametrize("name", ["veach", "bathroom"])
+def test_full_size_other_configs(gpu, name):
+    """BASELINE configs 3/4 at their real resolution (1280x720) and depth, spp 2: determinism,
+    counts, finiteness, and oracle parity on a 4-row band."""
+    data = scenes.veach_mis() if name == "veach" else scenes.bathroom()
+    depth = 100 if name == "veach" else 50
+    sc = api.Scene(data).upload(gpu)
+    a = sc.render(spp=2, max_depth=depth)
+    cnt = sc.counters()
+    assert cnt["samples"] == 1280 * 720 * 2
+    assert np.isfinite(a).all() and (a >= 0).all()
+    assert np.array_equal(a, sc.render(spp=2, max_depth=depth))
+    cpu, _ = oracle.Oracle(data).render(spp=2, max_depth=depth, rows=(400, 404), nthreads=8)
+    compare_images(a[400:404], cpu[400:404], max_bad_frac=2e-3)
