@@ -41,6 +41,9 @@
 #ifndef PRT_K3_KEEP
 #define PRT_K3_KEEP 24
 #endif
+#ifndef PRT_K1_WAVES
+#define PRT_K1_WAVES 4 // resident waves per SIMD the K1 register allocation leaves room for
+#endif
 #ifndef PRT_K1_CHUNK
 #define PRT_K1_CHUNK 1024
 #endif
@@ -58,7 +61,7 @@ __device__ __forceinline__ T wave_sum(T v) {
 // ends.  The stepping loop is left (and the finished lanes refilled) once no more than
 // PRT_K1_KEEP lanes are still traversing.
 template <bool COUNT>
-__global__ __launch_bounds__(PRT_BLOCK) void k_trace_closest(DScene S, const PrtRay* __restrict__ rays, size_t n,
+__global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScene S, const PrtRay* __restrict__ rays, size_t n,
                                                              PrtHit* __restrict__ hits, DCounters* ctr) {
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

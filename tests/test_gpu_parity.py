@@ -285,3 +285,62 @@ def test_full_size_other_configs(gpu, name):
     assert np.array_equal(a, sc.render(spp=2, max_depth=depth))
     cpu, _ = oracle.Oracle(data).render(spp=2, max_depth=depth, rows=(400, 404), nthreads=8)
     compare_images(a[400:404], cpu[400:404], max_bad_frac=2e-3)
+
+
+def _torture_scene():
+    """Degenerate inputs in one scene: a zero-area triangle (NaN normal -> vertex-normal / +z fallback,
+    Triangle.cpp:21-29), a triangle with identical texcoords (NaN tangent fallback, :39-46), a 1-channel
+    texture (grey, no sRGB decode, Texture.cpp:61-63), a missing texture (cyan, Texture.cpp:24), an
+    Empty absorber and a Debug emitter."""
+    b = scenes._Builder("torture")
+    b.textures.append((np.arange(16 * 16, dtype=np.uint8).reshape(16, 16) * 1).copy())   # 1 channel
+    b.textures.append(np.zeros((0, 0, 3), dtype=np.uint8))                                # no data -> (0,1,1)
+    grey = b.material(scenes.Material("Wood", _abi.MAT_LAMBERTIAN, kd=(0.5, 0.5, 0.5), texture=0))
+    cyan = b.material(scenes.Material("WoodFloor", _abi.MAT_LAMBERTIAN, kd=(0.5, 0.5, 0.5), texture=1))
+    white = b.material(scenes.Material("DiffuseWhite", _abi.MAT_LAMBERTIAN, kd=(0.8, 0.8, 0.8)))
+    light = b.material(scenes.Material("Light", _abi.MAT_DIFFUSE_LIGHT, emission=(9.0, 9.0, 9.0)))
+    empty = b.material(scenes.Material("quad1", _abi.MAT_EMPTY))
+    debug = b.material(scenes.Material("Debug", _abi.MAT_DEBUG, kd=(0.2, 0.1, 0.4)))
+    b.mesh("floor", grey, *scenes.quad((-1, -1, 1), (1, -1, 1), (1, -1, -1), (-1, -1, -1)))
+    b.mesh("back", cyan, *scenes.quad((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1)))
+    b.mesh("left", white, *scenes.quad((-1, -1, 1), (-1, -1, -1), (-1, 1, -1), (-1, 1, 1)))
+    b.mesh("light", light, *scenes.quad((-0.4, 0.99, -0.4), (0.4, 0.99, -0.4), (0.4, 0.99, 0.4), (-0.4, 0.99, 0.4)))
+    b.mesh("absorber", empty, *scenes.quad((0.2, -0.99, 0.0), (0.6, -0.99, 0.0), (0.6, -0.99, 0.4), (0.2, -0.99, 0.4)))
+    b.mesh("debug", debug, *scenes.quad((0.95, -0.5, -0.5), (0.95, -0.5, 0.5), (0.95, 0.5, 0.5), (0.95, 0.5, -0.5)))
+    # degenerate: zero-area triangle with a usable vertex normal, and one with all-equal UVs
+    deg_v = np.array([[[0, 0, 0], [0, 0, 0], [0.5, 0.5, 0]], [[-0.5, -0.9, 0.2], [0.0, -0.9, 0.2], [-0.25, -0.5, 0.2]]], dtype=np.float64)
+    deg_uv = np.array([[[0, 0], [1, 0], [0, 1]], [[0.3, 0.3], [0.3, 0.3], [0.3, 0.3]]], dtype=np.float64)
+    deg_n = np.array([[[0, 0, 1]] * 3, [[0, 0, 0]] * 3], dtype=np.float64)
+    b.mesh("degenerate", white, deg_v, deg_uv, deg_n)
+    return b.build(scenes.Camera(40, 32, 70.0, (0.03, 0.05, 1.6), (0.0, -0.2, 0.0)))
+
+
+def test_degenerate_inputs_and_textures(gpu):
+    data = _torture_scene()
+    cpu, _ = oracle.Oracle(data).render(spp=6, max_depth=6, seed=4)
+    assert np.isfinite(cpu).all()
+    sc = api.Scene(data).upload(gpu)
+    compare_images(sc.render(spp=6, max_depth=6, seed=4), cpu)
+    lo, hi = data.bounds()
+    rays = scenes.random_rays(20000, lo - 0.2, hi + 0.2, seed=8)
+    compare_hits(sc.trace_closest(rays), oracle.Oracle(data).trace_closest(rays))
+
+
+def test_empty_and_lightless_scenes(gpu):
+    # no triangles at all: every pixel is the background, every ray misses
+    b = scenes._Builder("empty")
+    b.material(scenes.Material("DiffuseWhite", _abi.MAT_LAMBERTIAN, kd=(0.5, 0.5, 0.5)))
+    empty = scenes.SceneData("empty", np.zeros((0, 3, 3)), np.zeros((0, 3, 2)), np.zeros((0, 3, 3)), np.array([0], dtype=np.uint64),
+                             np.zeros(0, dtype=np.int32), [], b.materials, scenes.Camera(16, 8, 60.0, (0, 0, 1), (0, 0, 0)))
+    sc = api.Scene(empty).upload(gpu)
+    img = sc.render(spp=3, max_depth=4, background=(0.25, 0.5, 0.75))
+    assert np.allclose(img, [0.25, 0.5, 0.75], rtol=1e-15)
+    h = sc.trace_closest(scenes.random_rays(100, (-1, -1, -1), (1, 1, 1)))
+    assert (h["prim"] == -1).all() and np.isinf(h["t"]).all()
+    # geometry but no emissive mesh, bSampleLights on: NEE is skipped, only the background lights the scene
+    from tests.test_oracle import one_triangle
+    one = one_triangle()
+    cpu, _ = oracle.Oracle(one).render(spp=8, max_depth=3, background=(0.3, 0.3, 0.3), sample_lights=False)
+    compare_images(api.Scene(one).upload(gpu).render(spp=8, max_depth=3, background=(0.3, 0.3, 0.3), sample_lights=False), cpu)
+    cpu2, _ = oracle.Oracle(one).render(spp=8, max_depth=3, background=(0.3, 0.3, 0.3), sample_lights=True)
+    compare_images(api.Scene(one).upload(gpu).render(spp=8, max_depth=3, background=(0.3, 0.3, 0.3), sample_lights=True), cpu2)
