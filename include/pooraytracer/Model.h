@@ -8,8 +8,9 @@
 //        .obj file in place, Model.cpp:195-276 — not reproduced);
 //   MTL: newmtl, Kd, Ks, Ns, map_Kd, map_Ks;
 //   XML: <light mtlname="..." radiance="r,g,b"/> (Model.cpp:332-360);
-//   textures: binary PPM/PGM (P6/P5) only — other formats load as the reference's "missing texture"
-//        (cyan, Texture.cpp:24); PNG/JPG decoding is a later row.
+//   textures: PNG (8-bit grey/grey+alpha/RGB/RGBA, non-interlaced; own inflate, png_decode.cpp) and binary
+//        PPM/PGM (P6/P5) — other formats (JPEG, 16-bit, palette, interlaced) load as the reference's
+//        "missing texture" (cyan, Texture.cpp:24).
 // Material type comes from the reference's name table (Model.cpp:16-51); unknown names are Lambertian.
 #pragma once
 #include <memory>

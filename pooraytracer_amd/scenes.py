@@ -433,7 +433,7 @@ def apply_loader_uv_fixup(scene: SceneData) -> SceneData:
     return out
 
 
-def export_obj(scene: SceneData, resources_dir: str, lights_only_table_names=True):
+def export_obj(scene: SceneData, resources_dir: str, texture_format="ppm"):
     """Write <resources_dir>/<name>/<name>.obj, .mtl, .xml (+ P6 .ppm textures) in the layout the
     reference reads (main.cpp:17-33).  Numbers are written with 17 significant
     digits so they round-trip exactly."""
@@ -445,10 +445,14 @@ def export_obj(scene: SceneData, resources_dir: str, lights_only_table_names=Tru
         for m in scene.materials:
             f.write(f"newmtl {m.name}\nKd {fmt(m.kd)}\nKs {fmt(m.ks)}\nNs {repr(float(m.ns))}\n")
             if m.texture >= 0:
-                f.write(f"map_Kd tex{m.texture}.ppm\n")
+                f.write(f"map_Kd tex{m.texture}.{texture_format}\n")
             f.write("\n")
     for i, t in enumerate(scene.textures):
         t = np.ascontiguousarray(t, dtype=np.uint8)
+        if texture_format == "png":
+            from PIL import Image
+            Image.fromarray(t).save(os.path.join(d, f"tex{i}.png"))  # zlib-compressed, adaptive filters
+            continue
         with open(os.path.join(d, f"tex{i}.ppm"), "wb") as f:
             f.write(f"P6\n{t.shape[1]} {t.shape[0]}\n255\n".encode())
             f.write(t.tobytes())

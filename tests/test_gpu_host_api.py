@@ -93,3 +93,20 @@ def test_obj_mtl_xml_loader_main_flow(gpu, tmp_path, scene_fn):
     ref = api.Scene(scenes.apply_loader_uv_fixup(data)).upload(gpu).render(spp=4, max_depth=6, seed=1)
     assert np.array_equal(img, ref)
     assert any(f.endswith(".png") for f in os.listdir(tmp_path)) and any(f.endswith(".hdr") for f in os.listdir(tmp_path))
+
+
+def test_loader_png_textures_match_ppm(gpu, tmp_path):
+    """Texture ingestion row: the same scene exported with PNG textures and with raw PPM textures must
+    render identically through the C++ loader (PNG decoded by the host library's own inflate)."""
+    build.build_host_example()
+    data = scenes.bathroom(48, 28, detail=0.08)
+    outs = []
+    for fmt in ("ppm", "png"):
+        res = str(tmp_path / fmt)
+        scenes.export_obj(data, res, texture_format=fmt)
+        out = str(tmp_path / f"{fmt}.f64")
+        r = subprocess.run([build.MAIN_EXE, res, data.name, "3", "5", str(tmp_path), out], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "Failed" not in r.stderr
+        outs.append(np.fromfile(out, dtype=np.float64))
+    assert np.array_equal(outs[0], outs[1])
