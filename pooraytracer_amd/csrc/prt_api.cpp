@@ -357,7 +357,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.rr = p->russian_roulette;
     P.inv_rr = 1.0 / p->russian_roulette;
     // wave scheduling thresholds (developer overrides through the environment for sweeps)
-    P.keep = 16;
+    P.keep = s->full_materials ? 16 : 24; // measured optima at the BASELINE spp (lean: 20-28 flat; full: 16)
     P.leaf_batch = 32;
     P.inner_min = 12;
     if (const char* e = std::getenv("PRT_TUNE_KEEP")) P.keep = std::atoi(e);
