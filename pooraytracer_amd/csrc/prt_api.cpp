@@ -48,7 +48,7 @@ struct PrtScene {
     std::vector<prt::HostTri> tris;
     std::vector<DMaterial> mats;
     std::vector<DTexture> texs;
-    std::vector<uint8_t> texels;
+    std::vector<double> texels_lin; // GetPixel() of every texel (Texture.cpp:50-65)
     prt::LightTree lights;
     prt::BuiltBVH bvh;
     // device side
@@ -148,8 +148,28 @@ int prt_scene_create(const PrtSceneDesc* desc, PrtScene** out) {
             o.height = t.height;
             o.channels = t.channels;
             o.has_data = (t.data && t.width > 0 && t.height > 0 && t.channels > 0) ? 1 : 0;
-            o.offset = s->texels.size();
-            if (o.has_data) s->texels.insert(s->texels.end(), t.data, t.data + (size_t)t.width * t.height * t.channels);
+            o.offset = s->texels_lin.size();
+            if (o.has_data) {
+                // ImageTexture::GetPixel: colorScale * byte, SRGBToLinear for >= 3 channels, grey replicated otherwise
+                double lut[256];
+                for (int b = 0; b < 256; ++b) {
+                    const double c = (1.0 / 255.0) * b;
+                    lut[b] = (c <= 0.04045) ? c * (1. / 12.92) : std::pow((c + 0.055) * (1. / 1.055), 2.4);
+                }
+                const size_t npx = (size_t)t.width * t.height;
+                s->texels_lin.reserve(s->texels_lin.size() + npx * 3);
+                for (size_t i = 0; i < npx; ++i) {
+                    const uint8_t* px = t.data + i * t.channels;
+                    if (t.channels >= 3) {
+                        s->texels_lin.push_back(lut[px[0]]);
+                        s->texels_lin.push_back(lut[px[1]]);
+                        s->texels_lin.push_back(lut[px[2]]);
+                    } else {
+                        const double g = (1.0 / 255.0) * px[0];
+                        s->texels_lin.insert(s->texels_lin.end(), {g, g, g});
+                    }
+                }
+            }
         }
         prt::build_light_tree(*desc, s->tris, s->mats, s->lights);
         std::string err;
@@ -223,11 +243,6 @@ int prt_scene_upload(PrtScene* s, int device) {
         b.material = T.material;
         b.prim = T.prim;
     }
-    std::vector<double> lut(256);
-    for (int i = 0; i < 256; ++i) { // ImageTexture::SRGBToLinear(colorScale * byte), Texture.cpp:52,66-70
-        const double c = (1.0 / 255.0) * i;
-        lut[i] = (c <= 0.04045) ? c * (1. / 12.92) : std::pow((c + 0.055) * (1. / 1.055), 2.4);
-    }
     DScene& d = s->d;
     std::memset(&d, 0, sizeof(d));
     int rc;
@@ -236,8 +251,7 @@ int prt_scene_upload(PrtScene* s, int device) {
     if ((rc = s->up(ds, &d.shade))) return rc;
     if ((rc = s->up(s->mats, &d.materials))) return rc;
     if ((rc = s->up(s->texs, &d.textures))) return rc;
-    if ((rc = s->up(s->texels, &d.texels))) return rc;
-    if ((rc = s->up(lut, &d.srgb_lut))) return rc;
+    if ((rc = s->up(s->texels_lin, &d.texels_lin))) return rc;
     if ((rc = s->up(s->lights.nodes, &d.light_nodes))) return rc;
     if ((rc = s->up(s->lights.tris, &d.light_tris))) return rc;
     d.light_root = s->lights.root;

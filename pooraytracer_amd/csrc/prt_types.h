@@ -7,7 +7,7 @@
 //   DTriShade[n_tris]   96 B  fp64 shading record in the same order (tangent, texcoords, material)
 //   DMaterial[n_mat]          material table (Material.h parameters)
 //   DLightNode/DLightTri      the reference's area-CDF light tree (BVH.cpp:86-100), exact fp64 areas
-//   texels / DTexture         8-bit texels + descriptors, 256-entry sRGB->linear LUT
+//   texels_lin / DTexture     per-texel GetPixel() result (3 doubles, sRGB->linear applied on the host) + descriptors
 #pragma once
 #include <stdint.h>
 
@@ -75,7 +75,7 @@ struct DMaterial {
 
 struct DTexture {
     int32_t width, height, channels, has_data;
-    uint64_t offset; // byte offset into the texel blob
+    uint64_t offset; // index of the texture's first double in texels_lin
 };
 
 struct DLightNode {
@@ -99,8 +99,7 @@ struct DScene {
     const DTriShade* shade;
     const DMaterial* materials;
     const DTexture* textures;
-    const uint8_t* texels;
-    const double* srgb_lut; // [256] SRGBToLinear(b/255) (Texture.cpp:66-70), computed on the host with std::pow
+    const double* texels_lin; // linearised texels, 3 doubles each: GetPixel() of Texture.cpp:50-65 evaluated on the host
     const DLightNode* light_nodes;
     const DLightTri* light_tris;
     int32_t light_root; // ref into light tree; valid iff n_lights > 0
