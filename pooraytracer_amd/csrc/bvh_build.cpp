@@ -20,7 +20,10 @@ namespace {
 
 constexpr int kBins = 16;
 constexpr int kMaxLevels = PRT_STACK_DEPTH - 2; // inner-node levels
-constexpr float kCostTri = 1.5f, kCostNode = 1.0f;
+#ifndef PRT_COST_TRI
+#define PRT_COST_TRI 1.5f
+#endif
+constexpr float kCostTri = PRT_COST_TRI, kCostNode = 1.0f; // a triangle test is 8 loads + an fp64 division, a node visit 2 loads
 
 struct PrimRef {
     float lo[3], hi[3];
