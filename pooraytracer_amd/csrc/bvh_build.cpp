@@ -18,7 +18,10 @@
 namespace prt {
 namespace {
 
-constexpr int kBins = 16;
+#ifndef PRT_SAH_BINS
+#define PRT_SAH_BINS 16
+#endif
+constexpr int kBins = PRT_SAH_BINS;
 constexpr int kMaxLevels = PRT_STACK_DEPTH - 2; // inner-node levels
 #ifndef PRT_COST_TRI
 #define PRT_COST_TRI 1.5f

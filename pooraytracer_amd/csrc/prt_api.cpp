@@ -396,7 +396,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     //  * explicit sample_chunks: that many equal chunks;
     //  * auto: a guided schedule — equal "body" chunks (enough items that the dynamic queue levels the
     //    load: >= 8 per resident lane, ~32-64 samples each) followed by a tail of halving chunks down to
-    //    4 samples, so the lanes that run out of items last are only a few rays behind.  Item fetches
+    //    single samples, so the lanes that run out of items last are only one path behind.  Item fetches
     //    (returning atomics, microseconds each) stay as rare as with the body size alone.
     std::vector<int> sizes;
     const int spp = p->spp;
@@ -411,10 +411,13 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
         body_chunks = std::max(body_chunks, std::min(32, (spp + 47) / 48));
         int body = std::max(1, spp / std::max(1, body_chunks));
         int left = spp;
-        // tail: 2 x body/2, 2 x body/4, ... , 4 x 4 samples (only when spp is large enough to matter)
+        // tail: 2 x body/2, 2 x body/4, ..., 2 x 4, 4 x 2, 8 x 1 samples.  The kernel ends when the
+        // LAST of ~200k concurrently running items ends, i.e. after the maximum (not the mean) item
+        // duration, and path lengths are heavy-tailed (up to max_depth+1 vertices): only 1-sample
+        // final items bound that drain time by one long path.
         std::vector<int> tail;
         if (spp >= 64) {
-            for (int sz = 4, n = 4; sz < body && (int)tail.size() < 16; sz *= 2, n = 2)
+            for (int sz = 1, n = 8; sz < body && (int)tail.size() < 28; sz *= 2, n = std::max(2, n / 2))
                 for (int k = 0; k < n; ++k) tail.push_back(sz);
         }
         int tail_sum = 0;

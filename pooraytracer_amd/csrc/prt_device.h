@@ -679,7 +679,10 @@ PRT_DEV bool owned_to_pixel(const DRenderParams& P, const DCamera& C, uint64_t o
     uint32_t ot = (uint32_t)(oi / tt), w = (uint32_t)(oi % tt);
     uint32_t k = (uint32_t)P.rank + ot * (uint32_t)P.nranks;
     if (k >= (uint32_t)P.n_tiles) return false;
-    uint32_t tx = k % (uint32_t)P.tiles_x, ty = k / (uint32_t)P.tiles_x;
+    // tile slot k -> tile (tx, ty): every tile row is rotated by 3*ty so that the tiles of one rank
+    // (k % nranks) form diagonals instead of fixed columns — better load balance across GPUs
+    const uint32_t kx = k % (uint32_t)P.tiles_x, ty = k / (uint32_t)P.tiles_x;
+    const uint32_t tx = (kx + 3u * ty) % (uint32_t)P.tiles_x;
     uint32_t bpr = (uint32_t)P.tile / 8u;
     uint32_t blk = w / 64u, l = w % 64u;
     px = (int)(tx * P.tile + (blk % bpr) * 8u + (l % 8u));

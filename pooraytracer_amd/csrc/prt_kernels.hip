@@ -347,8 +347,8 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
                     const uint32_t chunk = (uint32_t)(item / P.items_per_chunk);
                     const uint64_t oi = item % P.items_per_chunk;
                     if (owned_to_pixel(P, C, oi, px, py)) {
-                        s = (int)(((int64_t)chunk * P.spp) / P.chunks);
-                        s_end = (int)(((int64_t)(chunk + 1) * P.spp) / P.chunks);
+                        s = P.chunk_begin[chunk];
+                        s_end = P.chunk_begin[chunk + 1];
                         PST_ST(S_ACC, mk3(0, 0, 0));
                         if (s < s_end) state = ST_NEW_SAMPLE;
                         else {

@@ -8,11 +8,14 @@ import numpy as np
 
 def tile_owner_map(width, height, tile=32, nranks=1):
     """(H,W) int array: rank that renders each pixel.  Mirrors the device mapping in
-    csrc/prt_device.h owned_to_pixel(): tile k = ty*tiles_x + tx belongs to rank k % nranks."""
+    csrc/prt_device.h owned_to_pixel(): tile slot k = ty*tiles_x + kx belongs to rank k % nranks and
+    covers tile (tx, ty) with tx = (kx + 3*ty) % tiles_x (rows rotated so a rank's tiles form diagonals)."""
     tile = max(8, (tile + 7) // 8 * 8)
     tiles_x = (width + tile - 1) // tile
-    ty, tx = np.mgrid[0:height, 0:width]
-    k = (ty // tile) * tiles_x + (tx // tile)
+    py, px = np.mgrid[0:height, 0:width]
+    ty, tx = py // tile, px // tile
+    kx = (tx - 3 * ty) % tiles_x
+    k = ty * tiles_x + kx
     return (k % nranks).astype(np.int32)
 
 
