@@ -396,7 +396,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     //  * explicit sample_chunks: that many equal chunks;
     //  * auto: a guided schedule — equal "body" chunks (enough items that the dynamic queue levels the
     //    load: >= 8 per resident lane, ~32-64 samples each) followed by a tail of halving chunks down to
-    //    single samples, so the lanes that run out of items last are only one path behind.  Item fetches
+    //    8 samples, so the lanes that run out of items last are only a few paths behind.  Item fetches
     //    (returning atomics, microseconds each) stay as rare as with the body size alone.
     std::vector<int> sizes;
     const int spp = p->spp;
@@ -411,13 +411,17 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
         body_chunks = std::max(body_chunks, std::min(32, (spp + 47) / 48));
         int body = std::max(1, spp / std::max(1, body_chunks));
         int left = spp;
-        // tail: 2 x body/2, 2 x body/4, ..., 2 x 4, 4 x 2, 8 x 1 samples.  The kernel ends when the
-        // LAST of ~200k concurrently running items ends, i.e. after the maximum (not the mean) item
-        // duration, and path lengths are heavy-tailed (up to max_depth+1 vertices): only 1-sample
-        // final items bound that drain time by one long path.
+        // tail: 2 x body/2, 2 x body/4, ..., 4 x 8 samples.  The kernel ends when the LAST of ~200k
+        // concurrently running items ends, i.e. after the maximum (not the mean) item duration, and path
+        // lengths are heavy-tailed (up to max_depth+1 vertices), so the final items must be short.
         std::vector<int> tail;
         if (spp >= 64) {
-            for (int sz = 1, n = 8; sz < body && (int)tail.size() < 28; sz *= 2, n = std::max(2, n / 2))
+            // smallest tail item: 8 samples.  Every item fetch is a returning atomic that stalls its wave
+            // for microseconds (about one sample's worth of work per item), so below 8 samples the fetches
+            // cost more than the shorter drain saves (measured on N=1..8 tile shares at spp 500).
+            int tail_min = 8;
+            if (const char* e = std::getenv("PRT_TUNE_TAILMIN")) tail_min = std::max(1, std::atoi(e));
+            for (int sz = tail_min, n = (tail_min == 1 ? 8 : 4); sz < body && (int)tail.size() < 28; sz *= 2, n = std::max(2, n / 2))
                 for (int k = 0; k < n; ++k) tail.push_back(sz);
         }
         int tail_sum = 0;
