@@ -408,7 +408,9 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     } else {
         int body_chunks = 1;
         if (P.items_per_chunk) body_chunks = (int)std::min<uint64_t>(32, (8 * lanes + P.items_per_chunk - 1) / P.items_per_chunk);
-        body_chunks = std::max(body_chunks, std::min(32, (spp + 47) / 48));
+        int body_target = 128; // samples per body item (flat optimum 80-250 at spp 500; the 8-items-per-lane rule takes over on small shares)
+        if (const char* e = std::getenv("PRT_TUNE_BODY")) body_target = std::max(8, std::atoi(e));
+        body_chunks = std::max(body_chunks, std::min(32, (spp + body_target - 1) / body_target));
         int body = std::max(1, spp / std::max(1, body_chunks));
         int left = spp;
         // tail: 2 x body/2, 2 x body/4, ..., 4 x 8 samples.  The kernel ends when the LAST of ~200k
