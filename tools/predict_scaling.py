@@ -19,7 +19,7 @@ def main():
     for n in (2, 4, 8):
         ms = []
         for r in range(n):
-            sc.render_device(None, fb.data_ptr(), spp=spp, max_depth=depth, rank=r, nranks=n); torch.cuda.synchronize()
+            sc.render_device(None, fb.data_ptr(), spp=spp, max_depth=depth, rank=r, nranks=n, tile_size=int(os.environ.get("PS_TILE", "32"))); torch.cuda.synchronize()
             ms.append(sc.counters()["kernel_ms"])
         out[f"n{n}"] = {"max_ms": round(max(ms), 2), "mean_ms": round(sum(ms) / n, 2),
                         "balance": round(sum(ms) / n / max(ms), 4), "speedup_vs_full": round(full / max(ms), 3)}
