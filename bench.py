@@ -7,11 +7,12 @@ Workload at N=1 (BASELINE.json configs[1]): synthetic "cornell-box" stand-in (sc
 bSampleLights, seed 1, fp64 arithmetic (the reference's).  One "step" = one full frame
 (Camera::Render): K3 persistent path-tracing kernel + K5 finalize, inputs (scene, BVH) resident in HBM.
 
-N>1: one process per GPU (torch.distributed, backend nccl = RCCL).  The SAME frame is cut into 32x32
-tiles dealt round-robin over ranks (strong scaling: total work fixed); every rank renders its tiles
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL).  The SAME frame is cut into 16x16
+tiles dealt diagonally over ranks (strong scaling: total work fixed); every rank renders its tiles
 into a zero-initialised full-size fp32 framebuffer and one RCCL reduce(sum) to rank 0 assembles the
 image (disjoint tiles => x + 0 + ... + 0, bit-identical to the 1-GPU image).  The reduce is inside
-the timed region.
+the timed region.  Consecutive frames alternate between two HIP streams / framebuffers so the next
+frame fills the GPU while the previous one drains and is being reduced (--no-pipeline turns it off).
 
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline     dominant kernel k_render: algorithmic bytes per launch / mean launch duration measured
@@ -152,6 +153,7 @@ def main():
     ap.add_argument("--workload", default="cornell-box", choices=sorted(WORKLOADS) + sorted(RAY_WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override spp (0 = the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="one stream, one framebuffer: frames strictly back to back")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -175,8 +177,10 @@ def main():
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if nranks > 1:
+    force_dist = os.environ.get("PRT_BENCH_FORCE_DIST") == "1"  # test hook: RCCL process group even at N=1
+    if nranks > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if rehearsal:
             dist.init_process_group(backend="gloo", rank=rank, world_size=nranks)
         else:
@@ -196,39 +200,51 @@ def main():
     data = getattr(scenes, fn)(**kw)
     cam = data.camera
     sc = api.Scene(data).upload(local_rank)
-    fb = torch.zeros((cam.height, cam.width, 3), dtype=torch.float32, device="cuda")
+    # Two framebuffers on two HIP streams: consecutive frames alternate, so frame k+1 starts filling the
+    # GPU while the last long paths of frame k drain and its framebuffer is being reduced (RCCL overlaps
+    # with compute).  Every step is still one complete frame; libprt_hip double-buffers its per-call state.
+    pipelined = not args.no_pipeline and not rehearsal
+    fbs = [torch.zeros((cam.height, cam.width, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    fb = fbs[0]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()] if pipelined else [torch.cuda.current_stream()] * 2
     stream = torch.cuda.current_stream().cuda_stream
-    render_kw = dict(spp=spp, max_depth=depth, seed=seed, rank=rank, nranks=nranks, tile_size=32)
+    render_kw = dict(spp=spp, max_depth=depth, seed=seed, rank=rank, nranks=nranks, tile_size=16 if nranks > 1 else 32)
 
-    def step():
-        sc.render_device(None, fb.data_ptr(), stream=stream, **render_kw)
-        if rehearsal and nranks > 1:
-            host = fb.cpu()
-            distributed.reduce_framebuffer(host, dst=0)
-            fb.copy_(host)
-        else:
-            distributed.reduce_framebuffer(fb, dst=0)
+    def step(k, events=None):
+        st, buf = streams[k % 2], fbs[k % 2]
+        with torch.cuda.stream(st):
+            if events is not None:
+                events[0].record(st)
+            sc.render_device(None, buf.data_ptr(), stream=st.cuda_stream, **render_kw)
+            if events is not None:
+                events[1].record(st)
+            if rehearsal and nranks > 1:
+                host = buf.cpu()
+                distributed.reduce_framebuffer(host, dst=0)
+                buf.copy_(host)
+            else:
+                distributed.reduce_framebuffer(buf, dst=0)
 
     def fence():
-        if nranks > 1:
+        if nranks > 1 or force_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     fence()
-    kernel_ms = []
-    rays = 0
-    samples = 0
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        c = sc.counters()  # waits for this step's K3 (HIP events on the launch stream) and reads ray counters
-        kernel_ms.append(c["kernel_ms"])
-        rays += c["rays_closest"] + c["rays_shadow"]
-        samples += c["samples"]
+    for k in range(args.steps):
+        step(k, evs[k])
     fence()
     elapsed = time.perf_counter() - t0
+    # HIP events recorded on the stream each K3 was launched on (memsets + K3 + K5; K3 is > 99.9 % of it)
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+    c = sc.counters()  # ray counters of the last frame; every frame traces exactly the same rays (keyed RNG)
+    rays = (c["rays_closest"] + c["rays_shadow"]) * args.steps
+    samples = c["samples"] * args.steps
+    fb = fbs[(args.steps - 1) % 2]
 
     if nranks > 1:
         t = torch.tensor([elapsed, float(rays), float(samples)], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
@@ -247,6 +263,7 @@ def main():
               (nranks, "EQUALS" if torch.equal(assembled, fb) else "DIFFERS FROM"), file=sys.stderr, flush=True)
     if rank == 0:
         # counting instantiation (outside the timed region): mean node fetches / triangle tests per ray
+        torch.cuda.synchronize()
         sc.render_device(None, fb.data_ptr(), count_work=True, stream=stream,
                          **dict(render_kw, spp=min(spp, 8), rank=0, nranks=1))
         torch.cuda.synchronize()
@@ -274,7 +291,7 @@ def main():
             "config": {
                 "workload": f"{args.workload} (synthetic stand-in, {data.n_tris} tris) {cam.width}x{cam.height} "
                             f"spp={spp} depth={depth} rr=0.8 bSampleLights seed={seed}",
-                "parallelism": f"tiles32 round-robin over {nranks} GPU(s)" + (" + RCCL reduce(sum) of fp32 framebuffer" if nranks > 1 else ""),
+                "parallelism": f"{render_kw['tile_size']}x{render_kw['tile_size']} tiles dealt diagonally over {nranks} GPU(s)" + ("; frames pipelined on 2 streams" if pipelined else "") + (" + RCCL reduce(sum) of fp32 framebuffer" if nranks > 1 else ""),
                 "mpaths_per_s": round(samples / elapsed / 1e6, 3),
                 "rays_per_frame": int(rays / args.steps),
                 "s_per_frame": round(elapsed / args.steps, 4),
@@ -305,7 +322,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(data, spp, depth, seed)
             out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 1)
         print(json.dumps(out), flush=True)
-    if nranks > 1:
+    if nranks > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

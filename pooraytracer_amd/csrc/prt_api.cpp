@@ -58,12 +58,19 @@ struct PrtScene {
     bool full_materials = false; // needs the Phong / CookTorrance / texture kernel permutation
     DScene d{};
     std::vector<void*> allocs;
-    DCounters* d_ctr = nullptr;
-    double* d_partial = nullptr;
-    size_t partial_cap = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool timed = false;
-    bool counted = false;
+    // Per-call device state, double-buffered: consecutive calls alternate slots, so a caller that
+    // alternates two streams (and two framebuffers) can have frame k+1 filling the GPU while the last
+    // long paths of frame k drain — the two launches never share counters, partial sums or events.
+    struct CallSlot {
+        DCounters* d_ctr = nullptr;
+        double* d_partial = nullptr;
+        size_t partial_cap = 0;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        bool timed = false;
+        bool counted = false;
+    };
+    CallSlot slots[2];
+    int cur = 0; // slot of the most recent call (prt_get_counters reads it)
     PrtCounters last{};
 
     template <typename T>
@@ -80,14 +87,13 @@ struct PrtScene {
         if (device >= 0) (void)hipSetDevice(device);
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
-        if (d_ctr) (void)hipFree(d_ctr);
-        if (d_partial) (void)hipFree(d_partial);
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        d_ctr = nullptr;
-        d_partial = nullptr;
-        ev0 = ev1 = nullptr;
-        partial_cap = 0;
+        for (CallSlot& q : slots) {
+            if (q.d_ctr) (void)hipFree(q.d_ctr);
+            if (q.d_partial) (void)hipFree(q.d_partial);
+            if (q.ev0) (void)hipEventDestroy(q.ev0);
+            if (q.ev1) (void)hipEventDestroy(q.ev1);
+            q = CallSlot();
+        }
         device = -1;
     }
 };
@@ -264,10 +270,12 @@ int prt_scene_upload(PrtScene* s, int device) {
         d.grid_origin[a] = s->bvh.grid_origin[a];
         d.grid_step[a] = s->bvh.grid_step[a];
     }
-    PRT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_ctr), sizeof(DCounters)));
-    PRT_HIP(hipMemset(s->d_ctr, 0, sizeof(DCounters)));
-    PRT_HIP(hipEventCreate(&s->ev0));
-    PRT_HIP(hipEventCreate(&s->ev1));
+    for (PrtScene::CallSlot& q : s->slots) {
+        PRT_HIP(hipMalloc(reinterpret_cast<void**>(&q.d_ctr), sizeof(DCounters)));
+        PRT_HIP(hipMemset(q.d_ctr, 0, sizeof(DCounters)));
+        PRT_HIP(hipEventCreate(&q.ev0));
+        PRT_HIP(hipEventCreate(&q.ev1));
+    }
     s->full_materials = false;
     for (const DMaterial& m : s->mats)
         if (m.type == PRT_MAT_PHONG || m.type == PRT_MAT_COOKTORRANCE || m.texture >= 0) s->full_materials = true;
@@ -288,14 +296,16 @@ int prt_trace_closest_device(PrtScene* s, const void* d_rays, size_t n, void* d_
     if (rc) return rc;
     if (n && (!d_rays || !d_hits)) return fail(PRT_E_INVALID, "prt_trace_closest_device: null buffer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    PRT_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), st));
-    PRT_HIP(hipEventRecord(s->ev0, st));
-    prt::launch_trace(s->d, static_cast<const PrtRay*>(d_rays), n, static_cast<PrtHit*>(d_hits), s->d_ctr, count_work != 0,
+    s->cur ^= 1;
+    PrtScene::CallSlot& q = s->slots[s->cur];
+    PRT_HIP(hipMemsetAsync(q.d_ctr, 0, sizeof(DCounters), st));
+    PRT_HIP(hipEventRecord(q.ev0, st));
+    prt::launch_trace(s->d, static_cast<const PrtRay*>(d_rays), n, static_cast<PrtHit*>(d_hits), q.d_ctr, count_work != 0,
                       s->n_cu, st);
     PRT_HIP(hipGetLastError());
-    PRT_HIP(hipEventRecord(s->ev1, st));
-    s->timed = true;
-    s->counted = count_work != 0;
+    PRT_HIP(hipEventRecord(q.ev1, st));
+    q.timed = true;
+    q.counted = count_work != 0;
     return PRT_OK;
 }
 
@@ -443,31 +453,33 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.n_items = P.items_per_chunk * (uint64_t)chunks;
 
     const size_t need = std::max<size_t>(P.n_items * 3, 3);
-    if (need > s->partial_cap) {
-        if (s->d_partial) (void)hipFree(s->d_partial);
-        s->d_partial = nullptr;
-        s->partial_cap = 0;
-        PRT_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_partial), need * sizeof(double)));
-        s->partial_cap = need;
+    s->cur ^= 1;
+    PrtScene::CallSlot& q = s->slots[s->cur];
+    if (need > q.partial_cap) {
+        if (q.d_partial) (void)hipFree(q.d_partial); // hipFree waits for the device: nothing in flight reads it
+        q.d_partial = nullptr;
+        q.partial_cap = 0;
+        PRT_HIP(hipMalloc(reinterpret_cast<void**>(&q.d_partial), need * sizeof(double)));
+        q.partial_cap = need;
     }
     const size_t npx = (size_t)C.width * C.height * 3;
-    PRT_HIP(hipMemsetAsync(s->d_ctr, 0, sizeof(DCounters), st));
+    PRT_HIP(hipMemsetAsync(q.d_ctr, 0, sizeof(DCounters), st));
     if (d_rgb_f64) PRT_HIP(hipMemsetAsync(d_rgb_f64, 0, npx * sizeof(double), st));
     if (d_rgb_f32) PRT_HIP(hipMemsetAsync(d_rgb_f32, 0, npx * sizeof(float), st));
-    PRT_HIP(hipEventRecord(s->ev0, st));
+    PRT_HIP(hipEventRecord(q.ev0, st));
     if (P.n_items) {
         const uint64_t want = (P.n_items + PRT_BLOCK - 1) / PRT_BLOCK;
         const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)s->n_cu * bpc));
-        prt::launch_render(s->d, C, P, s->d_partial, s->d_ctr, count, s->full_materials, grid, st);
+        prt::launch_render(s->d, C, P, q.d_partial, q.d_ctr, count, s->full_materials, grid, st);
         PRT_HIP(hipGetLastError());
     }
-    PRT_HIP(hipEventRecord(s->ev1, st));
+    PRT_HIP(hipEventRecord(q.ev1, st));
     if (P.n_items) {
-        prt::launch_finalize(C, P, s->d_partial, static_cast<double*>(d_rgb_f64), static_cast<float*>(d_rgb_f32), st);
+        prt::launch_finalize(C, P, q.d_partial, static_cast<double*>(d_rgb_f64), static_cast<float*>(d_rgb_f32), st);
         PRT_HIP(hipGetLastError());
     }
-    s->timed = true;
-    s->counted = count;
+    q.timed = true;
+    q.counted = count;
     return PRT_OK;
 }
 
@@ -504,13 +516,14 @@ int prt_get_counters(PrtScene* s, PrtCounters* out) {
     PrtCounters c = s->last;
     c.bvh_nodes = s->bvh.nodes.size();
     c.bvh_depth = s->bvh.depth;
-    if (s->device >= 0 && s->timed) {
+    PrtScene::CallSlot& q = s->slots[s->cur];
+    if (s->device >= 0 && q.timed) {
         PRT_HIP(hipSetDevice(s->device));
-        PRT_HIP(hipEventSynchronize(s->ev1));
+        PRT_HIP(hipEventSynchronize(q.ev1));
         float ms = 0.f;
-        PRT_HIP(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        PRT_HIP(hipEventElapsedTime(&ms, q.ev0, q.ev1));
         DCounters h;
-        PRT_HIP(hipMemcpy(&h, s->d_ctr, sizeof(h), hipMemcpyDeviceToHost));
+        PRT_HIP(hipMemcpy(&h, q.d_ctr, sizeof(h), hipMemcpyDeviceToHost));
         c.rays_closest = h.rays_closest;
         c.rays_shadow = h.rays_shadow;
         c.node_fetches = h.node_fetches;

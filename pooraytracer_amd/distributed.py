@@ -27,6 +27,6 @@ def reduce_framebuffer(fb, dst=0):
     """Sum the per-rank framebuffers onto `dst`.  Disjoint tiles => every element is x + 0 + ... + 0,
     so the result is bit-identical to a single-rank render whatever the reduction order."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
     return fb
