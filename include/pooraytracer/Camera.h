@@ -36,6 +36,7 @@ public:
 
     // additions (not in the reference): RNG key, device index, counters of the last Render
     unsigned long long seed = 1;
+    bool bPixelJitter = false; // per-sample SampleSquare() pixel offset: the AA the reference has commented out (Camera.cpp:110-111)
     int device = 0;
     unsigned long long lastRays = 0;
     double lastKernelMs = 0.0;

@@ -112,6 +112,10 @@ typedef struct PrtRenderParams {
     int32_t tile_size;     /* multi-GPU tile edge in pixels (0 => 32) */
     int32_t rank, nranks;  /* this device renders tiles k with k % nranks == rank; others stay 0 */
     int32_t sample_chunks; /* 0 => auto; partial sums per pixel are combined in fixed order */
+    int32_t pixel_jitter;  /* 0 = reference behaviour (pixel centre).  1 = the anti-aliasing the reference has
+                              commented out (Camera.cpp:110-111): SampleSquare() offset, drawn per sample as
+                              the first two numbers of the sample's stream (offset.y first, offset.x second) */
+    int32_t reserved;      /* must be 0 */
 } PrtRenderParams;
 
 /* One ray of a batch: world.Hit(Ray(o,d), Interval(tmin,tmax)). */

@@ -40,7 +40,8 @@ class OrcCamera(C.Structure):
 class OrcRenderParams(C.Structure):
     _fields_ = [("spp", C.c_int32), ("max_depth", C.c_int32), ("russian_roulette", C.c_double),
                 ("sample_lights", C.c_int32), ("precision", C.c_int32), ("background", D3), ("seed", C.c_uint64),
-                ("tile_size", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32), ("sample_chunks", C.c_int32)]
+                ("tile_size", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32), ("sample_chunks", C.c_int32),
+                ("pixel_jitter", C.c_int32), ("reserved", C.c_int32)]
 
 
 class OrcCounters(C.Structure):
@@ -100,12 +101,13 @@ def _cam(cam):
     return c
 
 
-def _params(spp=1, max_depth=10, rr=0.8, sample_lights=True, background=(0.0, 0.0, 0.0), seed=1):
+def _params(spp=1, max_depth=10, rr=0.8, sample_lights=True, background=(0.0, 0.0, 0.0), seed=1, pixel_jitter=False):
     p = OrcRenderParams()
     p.spp, p.max_depth, p.russian_roulette = spp, max_depth, rr
     p.sample_lights = int(bool(sample_lights))
     p.background = D3(*background)
     p.seed, p.tile_size, p.rank, p.nranks = seed, 32, 0, 1
+    p.pixel_jitter = int(bool(pixel_jitter))
     return p
 
 

@@ -72,6 +72,8 @@ typedef struct OrcRenderParams {
     int32_t tile_size;
     int32_t rank, nranks;
     int32_t sample_chunks;
+    int32_t pixel_jitter; /* 0 = reference (pixel centre); 1 = SampleSquare offset per sample (Camera.cpp:110-111, disabled upstream) */
+    int32_t reserved;
 } OrcRenderParams;
 
 typedef struct OrcRay {

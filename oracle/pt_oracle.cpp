@@ -771,6 +771,16 @@ struct Camera {
         V3 viewportUpperLeft = center - (focalLength * w) - viewportU / 2. - viewportV / 2.;
         pixel00Location = viewportUpperLeft + 0.5 * (pixelDeltaU + pixelDeltaV);
     }
+    bool bPixelJitter = false;
+    // Camera.cpp:110-111 (commented out upstream): offset = SampleSquare() = dvec2(xi-0.5, xi-0.5)
+    // (RandomNumberGenerator.h:65-68); g++ evaluates the argument list right to left, so offset.y takes
+    // the first draw.  Upstream would call this once per pixel; here the offset is drawn per sample.
+    Ray GetRayJittered(int i, int j) const {
+        double oy = g_rng.next() - 0.5;
+        double ox = g_rng.next() - 0.5;
+        V3 pixelSample = pixel00Location + ((double)i + ox) * pixelDeltaU + ((double)j + oy) * pixelDeltaV;
+        return Ray{center, pixelSample - center};
+    }
     Ray GetRay(int i, int j) const { // Camera.cpp:108-117
         V3 pixelSample = pixel00Location + ((double)i) * pixelDeltaU + ((double)j) * pixelDeltaV;
         return Ray{center, pixelSample - center};
@@ -861,7 +871,7 @@ struct Tracer {
 
     V3 Sample(int i, int j, int s, uint64_t seed) {
         g_rng.seed(seed, (uint64_t)j * (uint64_t)cam.imageWidth + (uint64_t)i, (uint64_t)s);
-        Ray ray = cam.GetRay(i, j);
+        Ray ray = cam.bPixelJitter ? cam.GetRayJittered(i, j) : cam.GetRay(i, j);
         cnt.samples++;
         cnt.rays_closest++;
         return RayColor(ray, cam.maxDepth, nullptr);
@@ -881,6 +891,7 @@ Camera MakeCamera(const OrcCamera* c, const OrcRenderParams* p) {
     cam.up = V3{c->up[0], c->up[1], c->up[2]};
     cam.bSampleLights = p->sample_lights != 0;
     cam.russianRoulette = p->russian_roulette;
+    cam.bPixelJitter = p->pixel_jitter != 0;
     cam.Initialize();
     return cam;
 }

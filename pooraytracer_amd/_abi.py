@@ -91,6 +91,8 @@ class PrtRenderParams(C.Structure):
         ("rank", C.c_int32),
         ("nranks", C.c_int32),
         ("sample_chunks", C.c_int32),
+        ("pixel_jitter", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -218,10 +220,12 @@ def make_camera(cam, cls=PrtCamera):
 
 
 def make_params(cls=PrtRenderParams, spp=1, max_depth=10, rr=0.8, sample_lights=True, background=(0.0, 0.0, 0.0),
-                seed=1, tile_size=32, rank=0, nranks=1, sample_chunks=0, precision=0):
+                seed=1, tile_size=32, rank=0, nranks=1, sample_chunks=0, precision=0,
+                pixel_jitter=False):
     p = cls()
     p.spp, p.max_depth, p.russian_roulette = spp, max_depth, rr
     p.sample_lights, p.precision = int(bool(sample_lights)), precision
     p.background = D3(*background)
     p.seed, p.tile_size, p.rank, p.nranks, p.sample_chunks = seed, tile_size, rank, nranks, sample_chunks
+    p.pixel_jitter = int(bool(pixel_jitter))
     return p

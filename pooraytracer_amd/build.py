@@ -41,7 +41,7 @@ ROOT = os.path.dirname(HERE)
 
 def build_host_example(force=False):
     """g++ build of the C++ host API (include/pooraytracer/*.h over the C ABI) and the main.cpp-style driver."""
-    srcs = [os.path.join(HERE, "host", f) for f in ("host_api.cpp", "model.cpp", "png_decode.cpp")]
+    srcs = [os.path.join(HERE, "host", f) for f in ("host_api.cpp", "model.cpp", "png_decode.cpp", "jpeg_decode.cpp")]
     exe_src = os.path.join(ROOT, "examples", "render_scene.cpp")
     main_src = os.path.join(ROOT, "examples", "pooraytracer_main.cpp")
     inc = os.path.join(ROOT, "include")

@@ -397,6 +397,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.n_tiles = P.tiles_x * P.tiles_y;
     P.rank = p->rank;
     P.nranks = p->nranks;
+    P.jitter = p->pixel_jitter ? 1 : 0;
     P.owned_tiles = P.n_tiles > P.rank ? (P.n_tiles - P.rank + P.nranks - 1) / P.nranks : 0;
     P.items_per_chunk = (uint64_t)P.owned_tiles * tile * tile;
     const bool count = count_work != 0;

@@ -407,7 +407,12 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
             if (state == ST_NEW_SAMPLE) {
                 // per-sample stream keyed (seed, j*W+i, s); Camera::GetRay (Camera.cpp:108-117): pixel centre, no jitter
                 rng.seed(P.seed, (uint64_t)py * (uint64_t)C.width + (uint64_t)px, (uint64_t)s);
-                const d3 ps = ld3(C.pixel00) + ((double)px) * ld3(C.du) + ((double)py) * ld3(C.dv);
+                double fx = (double)px, fy = (double)py;
+                if (P.jitter) { // the disabled SampleSquare() offset of Camera.cpp:110-111, drawn per sample: y first (g++ argument order)
+                    fy += rng.next() - 0.5;
+                    fx += rng.next() - 0.5;
+                }
+                const d3 ps = ld3(C.pixel00) + fx * ld3(C.du) + fy * ld3(C.dv);
                 next_o = ld3(C.center);
                 next_d = ps - next_o;
                 PST_ST(S_L, mk3(0, 0, 0));

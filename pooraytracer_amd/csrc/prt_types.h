@@ -124,7 +124,7 @@ struct DRenderParams {
     double background[3];
     uint64_t seed;
     int32_t tile, tiles_x, tiles_y, n_tiles;
-    int32_t rank, nranks, owned_tiles, pad;
+    int32_t rank, nranks, owned_tiles, jitter; // jitter: per-sample SampleSquare pixel offset (Camera.cpp:110-111)
     int32_t keep, leaf_batch, inner_min, pad2; // wave scheduling thresholds of K3 (see prt_kernels.hip)
     uint64_t items_per_chunk; // owned_tiles * tile * tile
     uint64_t n_items;         // items_per_chunk * chunks

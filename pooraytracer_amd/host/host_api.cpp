@@ -302,6 +302,7 @@ void Camera::Render(Hittable& world, Hittable& lights) {
     p.tile_size = 32;
     p.rank = 0;
     p.nranks = 1;
+    p.pixel_jitter = bPixelJitter ? 1 : 0;
     std::vector<double> rgb((size_t)imageWidth * imageHeight * 3);
     check(prt_render(dc.scene, &c, &p, rgb.data(), nullptr), "prt_render");
     colorAttachment.assign((size_t)imageWidth * imageHeight, color(0., 0., 0.)); // cleared every frame

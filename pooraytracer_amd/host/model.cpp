@@ -79,15 +79,18 @@ std::vector<MtlRaw> load_mtl(const std::string& path) {
 
 } // namespace
 bool load_png(const std::string& path, int& w, int& h, int& channels, std::vector<unsigned char>& pixels); // png_decode.cpp
+bool load_jpeg(const std::string& path, int& w, int& h, int& channels, std::vector<unsigned char>& pixels); // jpeg_decode.cpp
 namespace {
 
-// ImageTexture(path), Texture.cpp:10-21, for PNG (8-bit, non-interlaced) and binary PPM/PGM; anything
-// else = failed load (no data), which renders as the reference's cyan "missing texture".
+// ImageTexture(path), Texture.cpp:10-21, for PNG (8-bit, non-interlaced), JPEG (baseline / progressive
+// Huffman, grey or colour) and binary PPM/PGM; anything else = failed load (no data), which renders as
+// the reference's cyan "missing texture".
 std::shared_ptr<Texture> load_texture(const std::string& path) {
     {
         int w = 0, h = 0, c = 0;
         std::vector<unsigned char> px;
         if (load_png(path, w, h, c, px)) return std::make_shared<ImageTexture>(w, h, c, px.data());
+        if (load_jpeg(path, w, h, c, px)) return std::make_shared<ImageTexture>(w, h, c, px.data());
     }
     std::ifstream f(path, std::ios::binary);
     std::string magic;

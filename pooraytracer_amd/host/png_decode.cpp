@@ -2,7 +2,7 @@
 // uses stb_image, Source/Texture.cpp:10-21).  Supports what texture assets use in practice: 8-bit
 // greyscale / grey+alpha / RGB / RGBA, non-interlaced; zlib streams with stored, fixed-Huffman and
 // dynamic-Huffman blocks.  Returns texels exactly like stbi_load(path, &w, &h, &channels, 0): interleaved,
-// row 0 first, file's own channel count.  Anything else (16-bit, palette, interlaced, JPEG, ...) fails
+// row 0 first, file's own channel count.  Anything else (16-bit, palette, interlaced, ...) fails
 // and the caller falls back to the reference's failed-load behaviour.
 #include <cstdint>
 #include <cstdio>

@@ -163,7 +163,8 @@ def test_render_options(gpu):
     sc = api.Scene(data).upload(gpu)
     orc = oracle.Oracle(data)
     for kw in (dict(spp=4, max_depth=5, sample_lights=False, background=(0.2, 0.3, 0.4)),
-               dict(spp=3, max_depth=0), dict(spp=4, max_depth=6, rr=1.0), dict(spp=5, max_depth=4, rr=0.5, seed=99)):
+               dict(spp=3, max_depth=0), dict(spp=4, max_depth=6, rr=1.0), dict(spp=5, max_depth=4, rr=0.5, seed=99),
+               dict(spp=6, max_depth=5, pixel_jitter=True, seed=5)):
         cpu, _ = orc.render(**kw)
         compare_images(sc.render(**kw), cpu)
     # chunked partial sums only change the summation order (<= 1e-15 relative)

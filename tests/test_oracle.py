@@ -145,6 +145,29 @@ def test_render_background_and_depth_zero():
     assert np.allclose(img[~miss], 0.0)
 
 
+def test_pixel_jitter_softens_edges_only():
+    """pixel_jitter=1 (the AA commented out at Camera.cpp:110-111): with depth 0 and a background, a pixel's
+    value is background x (fraction of jittered rays that miss).  Interior/exterior pixels are unchanged,
+    edge pixels become fractional, and the default (0) stays the reference's pixel-centre behaviour."""
+    sc = one_triangle()
+    o = oracle.Oracle(sc)
+    kw = dict(spp=64, max_depth=0, background=(1.0, 1.0, 1.0), sample_lights=False)
+    hard, _ = o.render(**kw)
+    soft, _ = o.render(pixel_jitter=True, **kw)
+    assert set(np.unique(hard)) <= {0.0, 1.0}
+    frac = (soft > 1e-9) & (soft < 1 - 1e-9)
+    assert frac.any()
+    # fractional pixels sit on the silhouette: a 3x3 neighbourhood of the hard image holds both values
+    jj, ii = np.nonzero(frac[..., 0])
+    for j, i in zip(jj, ii):
+        nb = hard[max(j - 1, 0):j + 2, max(i - 1, 0):i + 2, 0]
+        assert nb.min() == 0.0 and nb.max() == 1.0
+    assert abs(soft.mean() - hard.mean()) < 0.1  # tiny image: coverage is the same up to edge quantisation
+    # the offset uses the first two numbers of the sample stream: y first, then x
+    u = oracle.rng_stream(1, 0, 0, 2)
+    assert 0.0 <= u[0] < 1.0 and 0.0 <= u[1] < 1.0
+
+
 def test_peek_reuse_is_identical_and_threads_do_not_matter():
     sc = scenes.mixed_materials(24, 24)
     o = oracle.Oracle(sc)
