@@ -88,9 +88,14 @@ typedef struct PrtSceneDesc {
     const int32_t* mesh_material;   /* [n_meshes] index into materials */
     const PrtMaterial* materials;
     uint32_t n_textures;
-    uint32_t reserved;
+    uint32_t flags;          /* PRT_SCENE_* bits; 0 = defaults */
     const PrtTexture* textures;
 } PrtSceneDesc;
+
+/* Build the traversal BVH on the GPU at prt_scene_upload time instead of on the host at create time
+ * (reference: BVHNode constructors, Source/BVH.cpp:7-48, always CPU).  Results do not depend on the
+ * builder; the host builder stays the default because its trees traverse a few percent faster. */
+#define PRT_SCENE_DEVICE_BVH 1u
 
 /* Public camera fields of the reference, Source/Camera.h:14-24. */
 typedef struct PrtCamera {
@@ -158,6 +163,15 @@ typedef struct PrtCounters {
     uint64_t refills;       /* counting runs: wave-level shade/refill passes */
 } PrtCounters;
 
+/* Which builder made the traversal BVH and what it cost. */
+typedef struct PrtBvhInfo {
+    uint64_t n_nodes;
+    uint32_t depth;
+    uint32_t built_on_device;
+    double build_ms;  /* host builder: wall time inside prt_scene_create; device builder: HIP-event time */
+    double sort_ms, tree_ms, split_ms; /* device builder phases: Morton sort / box segment tree / SAH levels */
+} PrtBvhInfo;
+
 typedef struct PrtScene PrtScene;
 
 int prt_abi_version(void);
@@ -170,6 +184,8 @@ void prt_scene_destroy(PrtScene* scene);
 int prt_scene_upload(PrtScene* scene, int device);
 
 /* Number of light triangles and their order in the reference's area-CDF descent (BVH.cpp:86-100). */
+int prt_scene_bvh_info(const PrtScene* scene, PrtBvhInfo* out);
+
 int prt_scene_light_count(const PrtScene* scene, uint64_t* n);
 int prt_scene_light_order(const PrtScene* scene, int32_t* prims, uint64_t cap);
 

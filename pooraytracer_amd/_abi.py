@@ -62,8 +62,23 @@ class PrtSceneDesc(C.Structure):
         ("mesh_material", C.c_void_p),
         ("materials", C.c_void_p),
         ("n_textures", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("flags", C.c_uint32),
         ("textures", C.c_void_p),
+    ]
+
+
+PRT_SCENE_DEVICE_BVH = 1
+
+
+class PrtBvhInfo(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_uint64),
+        ("depth", C.c_uint32),
+        ("built_on_device", C.c_uint32),
+        ("build_ms", C.c_double),
+        ("sort_ms", C.c_double),
+        ("tree_ms", C.c_double),
+        ("split_ms", C.c_double),
     ]
 
 
@@ -156,6 +171,7 @@ EXPORTS = [
     "prt_scene_create",
     "prt_scene_destroy",
     "prt_scene_upload",
+    "prt_scene_bvh_info",
     "prt_scene_light_count",
     "prt_scene_light_order",
     "prt_trace_closest",

@@ -49,6 +49,7 @@ def load():
     L.prt_scene_destroy.argtypes = [vp]
     L.prt_scene_destroy.restype = None
     L.prt_scene_upload.argtypes = [vp, i32]
+    L.prt_scene_bvh_info.argtypes = [vp, vp]
     L.prt_scene_light_count.argtypes = [vp, C.POINTER(u64)]
     L.prt_scene_light_order.argtypes = [vp, vp, u64]
     L.prt_trace_closest.argtypes = [vp, vp, sz, vp, i32]
@@ -78,10 +79,12 @@ def device_count():
 class Scene:
     """A scene handle: host-side preparation at construction, `upload(device)` before any compute."""
 
-    def __init__(self, scene_data):
+    def __init__(self, scene_data, device_bvh=False):
         self.data = scene_data
         L = load()
         desc, keep = _abi.marshal_scene(scene_data)
+        if device_bvh:
+            desc.flags = _abi.PRT_SCENE_DEVICE_BVH  # tree built on the GPU in upload()
         h = C.c_void_p()
         _check(L.prt_scene_create(C.byref(desc), C.byref(h)))
         del keep  # the library copies everything it needs during create
@@ -103,6 +106,11 @@ class Scene:
         _check(load().prt_scene_upload(self._h, device))
         self.device = device
         return self
+
+    def bvh_info(self):
+        b = _abi.PrtBvhInfo()
+        _check(load().prt_scene_bvh_info(self._h, C.byref(b)))
+        return {f: getattr(b, f) for f, _ in _abi.PrtBvhInfo._fields_}
 
     def light_order(self):
         n = C.c_uint64(0)

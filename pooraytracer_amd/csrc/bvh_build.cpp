@@ -195,6 +195,32 @@ struct Builder {
 
 } // namespace
 
+void prim_boxes(const std::vector<HostTri>& tris, std::vector<PrimBox>& out) {
+    // small absolute inflation on top of the outward rounding (the kernel adds its own per-ray pad)
+    double scale = 1.0;
+    for (const HostTri& t : tris)
+        for (int a = 0; a < 3; ++a) scale = std::max(scale, std::max(std::fabs(t.lo[a]), std::fabs(t.hi[a])));
+    const double delta = 1e-9 * scale;
+    out.resize(tris.size());
+    for (size_t i = 0; i < tris.size(); ++i)
+        for (int a = 0; a < 3; ++a) {
+            out[i].lo[a] = round_down(tris[i].lo[a] - delta);
+            out[i].hi[a] = round_up(tris[i].hi[a] + delta);
+        }
+}
+
+void quant_grid(const float root_lo[3], const float root_hi[3], bool empty, float origin[3], float step[3]) {
+    for (int a = 0; a < 3; ++a) {
+        const double lo = empty ? 0.0 : (double)root_lo[a], hi = empty ? 1.0 : (double)root_hi[a];
+        const float o = round_down(lo);
+        float st = round_up((hi - (double)o) / 65535.0);
+        if (!(st > 0.f)) st = std::numeric_limits<float>::min();
+        while ((double)o + 65535.0 * (double)st < hi) st = std::nextafter(st, std::numeric_limits<float>::infinity());
+        origin[a] = o;
+        step[a] = st;
+    }
+}
+
 bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err) {
     out.nodes.clear();
     out.order.clear();
@@ -213,17 +239,14 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
     }
     Builder b(fn);
     b.prims.resize(n);
-    // small absolute inflation on top of the outward rounding (the kernel adds its own per-ray pad)
-    double scale = 1.0;
-    for (const HostTri& t : tris)
-        for (int a = 0; a < 3; ++a) scale = std::max(scale, std::max(std::fabs(t.lo[a]), std::fabs(t.hi[a])));
-    const double delta = 1e-9 * scale;
-    for (size_t i = 0; i < n; ++i) {
-        for (int a = 0; a < 3; ++a) {
-            b.prims[i].lo[a] = round_down(tris[i].lo[a] - delta);
-            b.prims[i].hi[a] = round_up(tris[i].hi[a] + delta);
+    {
+        std::vector<PrimBox> pb;
+        prim_boxes(tris, pb);
+        for (size_t i = 0; i < n; ++i) {
+            std::memcpy(b.prims[i].lo, pb[i].lo, sizeof(float) * 3);
+            std::memcpy(b.prims[i].hi, pb[i].hi, sizeof(float) * 3);
+            b.prims[i].idx = (uint32_t)i;
         }
-        b.prims[i].idx = (uint32_t)i;
     }
     FBox root;
     root.reset();
@@ -254,16 +277,10 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
     // quantisation grid over the root box: coordinate(q) = g0 + q * gs, evaluated in double here; the
     // kernel's float evaluation error is covered by its per-ray pad.  lo rounds down, hi rounds up.
     double g0[3], gs[3];
+    quant_grid(root.lo, root.hi, n == 0, out.grid_origin, out.grid_step);
     for (int a = 0; a < 3; ++a) {
-        const double lo = n ? (double)root.lo[a] : 0.0, hi = n ? (double)root.hi[a] : 1.0;
-        const float o = round_down(lo);
-        float st = round_up((hi - (double)o) / 65535.0);
-        if (!(st > 0.f)) st = std::numeric_limits<float>::min();
-        while ((double)o + 65535.0 * (double)st < hi) st = std::nextafter(st, std::numeric_limits<float>::infinity());
-        out.grid_origin[a] = o;
-        out.grid_step[a] = st;
-        g0[a] = o;
-        gs[a] = st;
+        g0[a] = out.grid_origin[a];
+        gs[a] = out.grid_step[a];
     }
     auto qlo = [&](float v, int a) -> uint16_t {
         double q = std::floor(((double)v - g0[a]) / gs[a]);

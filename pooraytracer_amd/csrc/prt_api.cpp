@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <string>
@@ -25,6 +26,8 @@ void launch_finalize(const DCamera& C, const DRenderParams& P, const double* d_p
 void launch_sample_lights(const DScene& S, const double* d_origins, size_t n, uint64_t seed, PrtLightSample* d_out,
                           hipStream_t st);
 void launch_tonemap(const float* d_in, size_t n, uint8_t* d_out, hipStream_t st);
+void launch_gather_tris(const DTri* tri_in, const DTriShade* shade_in, const uint32_t* order, uint32_t n, DTri* tri_out,
+                        DTriShade* shade_out, hipStream_t st);
 } // namespace prt
 
 namespace {
@@ -51,6 +54,8 @@ struct PrtScene {
     std::vector<double> texels_lin; // GetPixel() of every texel (Texture.cpp:50-65)
     prt::LightTree lights;
     prt::BuiltBVH bvh;
+    bool device_bvh = false; // PRT_SCENE_DEVICE_BVH: the tree is built in prt_scene_upload, on the GPU
+    PrtBvhInfo bvh_info{};
     // device side
     int device = -1;
     int n_cu = 0;
@@ -178,10 +183,15 @@ int prt_scene_create(const PrtSceneDesc* desc, PrtScene** out) {
             }
         }
         prt::build_light_tree(*desc, s->tris, s->mats, s->lights);
-        std::string err;
-        if (!prt::build_bvh(s->tris, s->bvh, &err)) {
-            delete s;
-            return fail(PRT_E_LIMIT, "prt_scene_create: " + err);
+        s->device_bvh = (desc->flags & PRT_SCENE_DEVICE_BVH) && s->tris.size() >= 2;
+        if (!s->device_bvh) {
+            std::string err;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (!prt::build_bvh(s->tris, s->bvh, &err)) {
+                delete s;
+                return fail(PRT_E_LIMIT, "prt_scene_create: " + err);
+            }
+            s->bvh_info.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
     } catch (const std::bad_alloc&) {
         delete s;
@@ -192,6 +202,8 @@ int prt_scene_create(const PrtSceneDesc* desc, PrtScene** out) {
     }
     s->last.bvh_nodes = s->bvh.nodes.size();
     s->last.bvh_depth = s->bvh.depth;
+    s->bvh_info.n_nodes = s->bvh.nodes.size();
+    s->bvh_info.depth = s->bvh.depth;
     *out = s;
     return PRT_OK;
 }
@@ -200,6 +212,12 @@ void prt_scene_destroy(PrtScene* s) {
     if (!s) return;
     s->release();
     delete s;
+}
+
+int prt_scene_bvh_info(const PrtScene* s, PrtBvhInfo* out) {
+    if (!s || !out) return fail(PRT_E_INVALID, "prt_scene_bvh_info: null argument");
+    *out = s->bvh_info;
+    return PRT_OK;
 }
 
 int prt_scene_light_count(const PrtScene* s, uint64_t* n) {
@@ -232,7 +250,7 @@ int prt_scene_upload(PrtScene* s, int device) {
     std::vector<DTri> dt(n);
     std::vector<DTriShade> ds(n);
     for (size_t i = 0; i < n; ++i) {
-        const prt::HostTri& T = s->tris[s->bvh.order[i]];
+        const prt::HostTri& T = s->tris[s->device_bvh ? i : s->bvh.order[i]]; // device build: permuted on the GPU below
         DTri& a = dt[i];
         std::memcpy(a.n, T.normal, 24);
         a.D = T.D;
@@ -252,9 +270,62 @@ int prt_scene_upload(PrtScene* s, int device) {
     DScene& d = s->d;
     std::memset(&d, 0, sizeof(d));
     int rc;
-    if ((rc = s->up(s->bvh.nodes, &d.nodes))) return rc;
-    if ((rc = s->up(dt, &d.tris))) return rc;
-    if ((rc = s->up(ds, &d.shade))) return rc;
+    if (s->device_bvh) {
+        std::vector<prt::PrimBox> pb;
+        prt::prim_boxes(s->tris, pb);
+        prt::DeviceBVH db;
+        std::string err;
+        if (!prt::build_bvh_device(pb.data(), n, db, &err)) return fail(PRT_E_HIP, "prt_scene_upload: " + err);
+        s->allocs.push_back(db.d_nodes);
+        d.nodes = db.d_nodes;
+        // records go up in description order and are permuted into BVH leaf order in HBM
+        const DTri* t_in = nullptr;
+        const DTriShade* s_in = nullptr;
+        void *t_out = nullptr, *s_out = nullptr;
+        const size_t mark = s->allocs.size();
+        rc = s->up(dt, &t_in);
+        if (!rc) rc = s->up(ds, &s_in);
+        hipError_t e = hipSuccess;
+        if (!rc) {
+            e = hipMalloc(&t_out, n * sizeof(DTri));
+            if (e == hipSuccess) { s->allocs.push_back(t_out); e = hipMalloc(&s_out, n * sizeof(DTriShade)); }
+            if (e == hipSuccess) {
+                s->allocs.push_back(s_out);
+                prt::launch_gather_tris(t_in, s_in, db.d_order, (uint32_t)n, static_cast<DTri*>(t_out),
+                                        static_cast<DTriShade*>(s_out), nullptr);
+                e = hipGetLastError();
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+            }
+        }
+        (void)hipFree(db.d_order);
+        // drop the two staging copies (they sit at allocs[mark], allocs[mark+1] when their upload succeeded)
+        for (const void* p : {static_cast<const void*>(t_in), static_cast<const void*>(s_in)})
+            if (p) {
+                (void)hipFree(const_cast<void*>(p));
+                s->allocs.erase(std::find(s->allocs.begin() + mark, s->allocs.end(), const_cast<void*>(p)));
+            }
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? PRT_E_OOM : PRT_E_HIP, std::string("prt_scene_upload: ") + hipGetErrorString(e));
+        d.tris = static_cast<const DTri*>(t_out);
+        d.shade = static_cast<const DTriShade*>(s_out);
+        s->bvh.depth = db.depth;
+        s->bvh.coord_scale = db.coord_scale;
+        for (int a = 0; a < 3; ++a) {
+            s->bvh.grid_origin[a] = db.grid_origin[a];
+            s->bvh.grid_step[a] = db.grid_step[a];
+        }
+        s->last.bvh_nodes = s->bvh_info.n_nodes = db.n_nodes;
+        s->last.bvh_depth = s->bvh_info.depth = db.depth;
+        s->bvh_info.built_on_device = 1;
+        s->bvh_info.build_ms = db.ms_total;
+        s->bvh_info.sort_ms = db.ms_sort;
+        s->bvh_info.tree_ms = db.ms_tree;
+        s->bvh_info.split_ms = db.ms_split;
+    } else {
+        if ((rc = s->up(s->bvh.nodes, &d.nodes))) return rc;
+        if ((rc = s->up(dt, &d.tris))) return rc;
+        if ((rc = s->up(ds, &d.shade))) return rc;
+    }
     if ((rc = s->up(s->mats, &d.materials))) return rc;
     if ((rc = s->up(s->texs, &d.textures))) return rc;
     if ((rc = s->up(s->texels_lin, &d.texels_lin))) return rc;
@@ -263,7 +334,7 @@ int prt_scene_upload(PrtScene* s, int device) {
     d.light_root = s->lights.root;
     d.n_lights = (int32_t)s->lights.tris.size();
     d.light_area = s->lights.area;
-    d.n_nodes = (uint32_t)s->bvh.nodes.size();
+    d.n_nodes = s->device_bvh ? (uint32_t)s->bvh_info.n_nodes : (uint32_t)s->bvh.nodes.size();
     d.n_tris = (uint32_t)n;
     d.coord_scale = s->bvh.coord_scale;
     for (int a = 0; a < 3; ++a) {

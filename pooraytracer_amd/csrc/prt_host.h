@@ -29,6 +29,24 @@ struct BuiltBVH {
     float grid_origin[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1}; // PRT_NODE16 quantisation grid
 };
 
+// fp32 box of one triangle for the BVH builders: HostTri::lo/hi rounded outward + a small absolute inflation
+struct PrimBox {
+    float lo[3], hi[3];
+};
+void prim_boxes(const std::vector<HostTri>& tris, std::vector<PrimBox>& out);
+// PRT_NODE16 quantisation grid over the root box (origin rounds down, 65535 steps reach past hi).
+void quant_grid(const float root_lo[3], const float root_hi[3], bool empty, float origin[3], float step[3]);
+
+// BVH built on the device (bvh_build_gpu.hip): nodes and the triangle permutation stay in HBM.
+struct DeviceBVH {
+    DNode* d_nodes = nullptr;    // hipMalloc'ed, n_nodes entries (caller owns)
+    uint32_t* d_order = nullptr; // hipMalloc'ed, n entries: BVH leaf order -> index into the HostTri array
+    uint32_t n_nodes = 0, depth = 0;
+    float coord_scale = 1.0f;
+    float grid_origin[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1};
+    double ms_sort = 0, ms_tree = 0, ms_split = 0, ms_total = 0; // hipEvent times of the build phases
+};
+
 struct LightTree {
     std::vector<DLightNode> nodes;
     std::vector<DLightTri> tris; // in area-CDF (leaf) order
@@ -43,6 +61,9 @@ void setup_materials(const PrtSceneDesc& d, std::vector<DMaterial>& out);
 // Binned-SAH BVH2, depth-bounded to PRT_STACK_DEPTH, child boxes rounded outward to fp32.
 // Returns false (with *err set) if a compiled-in limit is exceeded.
 bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err);
+// Same tree family built on the current HIP device from the same fp32 boxes (n >= 2): Morton sort, box
+// segment tree, level-synchronous SAH splits along the Morton order.  Returns false with *err set.
+bool build_bvh_device(const PrimBox* h_boxes, size_t n, DeviceBVH& out, std::string* err);
 // The reference's lights object graph (main.cpp:36-45, BVH.cpp:7-48) reduced to what
 // BVHNode::Sample/TraverseSample read: per-node left area + children, leaves in CDF order.
 void build_light_tree(const PrtSceneDesc& d, const std::vector<HostTri>& tris, const std::vector<DMaterial>& mats,

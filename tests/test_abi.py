@@ -25,9 +25,9 @@ def test_header_symbols_all_exported(prt_lib):
 def test_struct_layouts_match_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
-        '#include <stdio.h>\n#include "prt.h"\n#include "oracle.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+        '#include <stdio.h>\n#include "prt.h"\n#include "oracle.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
         "sizeof(PrtMaterial),sizeof(PrtTexture),sizeof(PrtSceneDesc),sizeof(PrtCamera),sizeof(PrtRenderParams),"
-        "sizeof(PrtRay),sizeof(PrtHit),sizeof(PrtLightSample),sizeof(PrtCounters));"
+        "sizeof(PrtRay),sizeof(PrtHit),sizeof(PrtLightSample),sizeof(PrtCounters),sizeof(PrtBvhInfo));"
         'printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",sizeof(OrcMaterial),sizeof(OrcTexture),sizeof(OrcSceneDesc),'
         "sizeof(OrcCamera),sizeof(OrcRenderParams),sizeof(OrcRay),sizeof(OrcHit),sizeof(OrcLightSample));return 0;}\n")
     exe = tmp_path / "sz"
@@ -36,7 +36,8 @@ def test_struct_layouts_match_header(tmp_path):
     prt_sizes = [int(x) for x in a.split()]
     orc_sizes = [int(x) for x in b.split()]
     py = [C.sizeof(t) for t in (_abi.PrtMaterial, _abi.PrtTexture, _abi.PrtSceneDesc, _abi.PrtCamera,
-                                _abi.PrtRenderParams, _abi.PrtRay, _abi.PrtHit, _abi.PrtLightSample, _abi.PrtCounters)]
+                                _abi.PrtRenderParams, _abi.PrtRay, _abi.PrtHit, _abi.PrtLightSample, _abi.PrtCounters,
+                                _abi.PrtBvhInfo)]
     assert prt_sizes == py
     assert orc_sizes == py[:8]
 
@@ -47,6 +48,14 @@ def test_scene_create_and_light_order_without_gpu(prt_lib):
     assert sorted(order.tolist()) == [10, 11]  # the two triangles of the ceiling light quad
     cnt = sc.counters()
     assert cnt["bvh_nodes"] >= 1 and cnt["bvh_depth"] <= 30
+    info = sc.bvh_info()
+    assert info["n_nodes"] == cnt["bvh_nodes"] and info["built_on_device"] == 0 and info["build_ms"] >= 0
+    sc.close()
+    # PRT_SCENE_DEVICE_BVH defers the build to upload(): create succeeds without a GPU, nothing is built yet
+    sc = api.Scene(scenes.tiny_scene(), device_bvh=True)
+    assert sc.bvh_info()["n_nodes"] == 0
+    with pytest.raises(api.PrtError):
+        sc.upload(0)
     sc.close()
 
 
