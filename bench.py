@@ -11,12 +11,14 @@ N>1: one process per GPU (torch.distributed, backend nccl = RCCL).  The SAME fra
 tiles dealt diagonally over ranks (strong scaling: total work fixed); every rank renders its tiles
 into a zero-initialised full-size fp32 framebuffer and one RCCL reduce(sum) to rank 0 assembles the
 image (disjoint tiles => x + 0 + ... + 0, bit-identical to the 1-GPU image).  The reduce is inside
-the timed region.  Consecutive frames alternate between two HIP streams / framebuffers so the next
-frame fills the GPU while the previous one drains and is being reduced (--no-pipeline turns it off).
+the timed region.  For N>1 consecutive frames alternate between two HIP streams / framebuffers so the
+next frame fills the GPU while the previous one drains and is being reduced (--no-pipeline turns it
+off; at N=1 frames run back to back on one stream unless --pipeline is given).
 
 Prints ONE JSON line on rank 0.  Extra objects:
   roofline     dominant kernel k_render: algorithmic bytes per launch / mean launch duration measured
-               live with HIP events on the launch stream (library-side hipEventRecord around K3).
+               live with HIP events on the launch stream around every launch of the timed region
+               (overlapped launches, N>1 only: the launch period instead, see kernel_ms_source).
   cpu_baseline the CPU oracle (port of the reference algorithm, oracle/pt_oracle.cpp) timed on this
                box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -154,6 +156,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override spp (0 = the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one stream, one framebuffer: frames strictly back to back")
+    ap.add_argument("--pipeline", action="store_true", help="alternate two streams / framebuffers also at N=1 (default: only for N>1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -203,7 +206,12 @@ def main():
     # Two framebuffers on two HIP streams: consecutive frames alternate, so frame k+1 starts filling the
     # GPU while the last long paths of frame k drain and its framebuffer is being reduced (RCCL overlaps
     # with compute).  Every step is still one complete frame; libprt_hip double-buffers its per-call state.
-    pipelined = not args.no_pipeline and not rehearsal
+    # Pipelining is for N > 1 (a 1/N tile share makes the fixed fill+drain of a launch matter; at N = 1 it is
+    # worth 2 %).  At N = 1 the frames run back to back on one stream so that the HIP events around each launch
+    # bracket exactly that launch: overlapped launches would each be timed from submission, i.e. including the
+    # wait for the previous frame's wave slots (measured: 834 ms per launch for a 418 ms launch period), and the
+    # roofline below would be computed from a duration that is not the kernel's.  --pipeline forces it on.
+    pipelined = (args.pipeline or nranks > 1) and not args.no_pipeline and not rehearsal
     fbs = [torch.zeros((cam.height, cam.width, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
     fb = fbs[0]
     streams = [torch.cuda.Stream(), torch.cuda.Stream()] if pipelined else [torch.cuda.current_stream()] * 2
@@ -273,6 +281,10 @@ def main():
         bpr = bytes_per_ray(npr, tpr)
         rays_per_launch = rays / args.steps / nranks  # this rank's launch (tiles are balanced round-robin)
         mean_ms = sum(kernel_ms) / len(kernel_ms)
+        if pipelined:
+            # overlapped launches: an event pair spans the queueing behind the previous frame as well, so the
+            # launch PERIOD (timed region / launches) is the per-launch duration the roofline is priced with
+            mean_ms = elapsed * 1e3 / args.steps
         fb_bytes = 24.0 * cam.width * cam.height / nranks  # fp64 per-item partial sums written by K3
         achieved = (bpr * rays_per_launch + fb_bytes) / (mean_ms * 1e-3) / 1e9
         out = {
@@ -305,6 +317,7 @@ def main():
                 "traffic": None,
                 "kernel": "k_render",
                 "kernel_ms": round(mean_ms, 3),
+                "kernel_ms_source": "launch period of overlapped launches" if pipelined else "HIP events around each launch",
                 "bytes_per_ray": round(bpr, 1),
                 "nodes_per_ray": round(npr, 2),
                 "tris_per_ray": round(tpr, 2),

@@ -36,6 +36,7 @@ public:
 
     // additions (not in the reference): RNG key, device index, counters of the last Render
     unsigned long long seed = 1;
+    bool bBuildBvhOnDevice = false; // PRT_SCENE_DEVICE_BVH: build the traversal BVH on the GPU (first Render of a world)
     bool bPixelJitter = false; // per-sample SampleSquare() pixel offset: the AA the reference has commented out (Camera.cpp:110-111)
     int device = 0;
     unsigned long long lastRays = 0;

@@ -16,11 +16,12 @@
 #include "prt_host.h"
 
 namespace prt {
-int render_blocks_per_cu(bool count, bool full);
+int render_blocks_per_cu(bool count, int feat);
+int render_permutation(int feat);
 void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hits, DCounters* d_ctr, bool count, int n_cu,
                   hipStream_t st);
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
-                   bool count, bool full, unsigned grid, hipStream_t st);
+                   bool count, int feat, unsigned grid, hipStream_t st);
 void launch_finalize(const DCamera& C, const DRenderParams& P, const double* d_partial, double* d64, float* d32,
                      hipStream_t st);
 void launch_sample_lights(const DScene& S, const double* d_origins, size_t n, uint64_t seed, PrtLightSample* d_out,
@@ -60,7 +61,7 @@ struct PrtScene {
     int device = -1;
     int n_cu = 0;
     int blocks_per_cu[2] = {0, 0};
-    bool full_materials = false; // needs the Phong / CookTorrance / texture kernel permutation
+    int feat = 0; // material features of the scene (1 textures, 2 Phong, 4 CookTorrance) -> K3 permutation
     DScene d{};
     std::vector<void*> allocs;
     // Per-call device state, double-buffered: consecutive calls alternate slots, so a caller that
@@ -347,11 +348,16 @@ int prt_scene_upload(PrtScene* s, int device) {
         PRT_HIP(hipEventCreate(&q.ev0));
         PRT_HIP(hipEventCreate(&q.ev1));
     }
-    s->full_materials = false;
-    for (const DMaterial& m : s->mats)
-        if (m.type == PRT_MAT_PHONG || m.type == PRT_MAT_COOKTORRANCE || m.texture >= 0) s->full_materials = true;
-    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->full_materials);
-    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->full_materials);
+    s->feat = 0;
+    for (const DMaterial& m : s->mats) {
+        if (m.texture >= 0) s->feat |= 1;
+        if (m.type == PRT_MAT_PHONG) s->feat |= 2;
+        if (m.type == PRT_MAT_COOKTORRANCE) s->feat |= 4;
+    }
+    if (const char* e = std::getenv("PRT_TUNE_FEAT")) s->feat |= std::atoi(e); // developer: force a larger permutation
+    s->feat = prt::render_permutation(s->feat);
+    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat);
+    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat);
     return PRT_OK;
 }
 
@@ -452,7 +458,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.rr = p->russian_roulette;
     P.inv_rr = 1.0 / p->russian_roulette;
     // wave scheduling thresholds (developer overrides through the environment for sweeps)
-    P.keep = s->full_materials ? 16 : 24; // measured optima at the BASELINE spp (lean: 20-28 flat; full: 16)
+    P.keep = s->feat == 0 ? 24 : 16; // measured optima at the BASELINE spp (lean: 20-28 flat; others: 16)
     P.leaf_batch = 32;
     P.inner_min = 12;
     if (const char* e = std::getenv("PRT_TUNE_KEEP")) P.keep = std::atoi(e);
@@ -476,10 +482,16 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     const uint64_t lanes = (uint64_t)s->n_cu * bpc * PRT_BLOCK;
     // Work item = (pixel, chunk of samples), dealt chunk-major from one global counter.
     //  * explicit sample_chunks: that many equal chunks;
-    //  * auto: a guided schedule — equal "body" chunks (enough items that the dynamic queue levels the
-    //    load: >= 8 per resident lane, ~32-64 samples each) followed by a tail of halving chunks down to
-    //    8 samples, so the lanes that run out of items last are only a few paths behind.  Item fetches
-    //    (returning atomics, microseconds each) stay as rare as with the body size alone.
+    //  * auto: guided self-scheduling.  The launch ends when the LAST lane finishes, so no item may be
+    //    handed out that can outlast the work still queued behind it.  Items of one chunk cover every owned
+    //    pixel, pixels differ in cost by a factor `var` (a pixel looking into the box interior traces ~3x the
+    //    rays of the average one), and `lanes` lanes drain the queue, so chunk j may hold at most
+    //        s_j <= (pixels / lanes) / var * (samples in all later chunks)
+    //    samples.  Built from the last chunk (1 sample) backwards this gives a geometric tail whose ratio
+    //    depends on the share: x2.8 per chunk for a full 1024^2 frame, x1.2 for a 1/8 tile share — where
+    //    a fixed halving tail left lanes finishing 32-sample items 5.8 ms after the queue ran dry (measured
+    //    with per-wave timestamps: 58.3 ms launch, queue dry at 52.5 ms).  Sizes are capped at `body`
+    //    samples; the per-item fetch is one wave-aggregated atomic.
     std::vector<int> sizes;
     const int spp = p->spp;
     int want = p->sample_chunks;
@@ -487,34 +499,28 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     if (want > 0) {
         want = std::min(want, std::min(spp, PRT_MAX_CHUNKS));
         for (int c = 0; c < want; ++c) sizes.push_back((int)(((int64_t)(c + 1) * spp) / want - ((int64_t)c * spp) / want));
+    } else if (P.items_per_chunk == 0) {
+        sizes.push_back(spp);
     } else {
-        int body_chunks = 1;
-        if (P.items_per_chunk) body_chunks = (int)std::min<uint64_t>(32, (8 * lanes + P.items_per_chunk - 1) / P.items_per_chunk);
-        int body_target = 128; // samples per body item (flat optimum 80-250 at spp 500; the 8-items-per-lane rule takes over on small shares)
-        if (const char* e = std::getenv("PRT_TUNE_BODY")) body_target = std::max(8, std::atoi(e));
-        body_chunks = std::max(body_chunks, std::min(32, (spp + body_target - 1) / body_target));
-        int body = std::max(1, spp / std::max(1, body_chunks));
-        int left = spp;
-        // tail: 2 x body/2, 2 x body/4, ..., 4 x 8 samples.  The kernel ends when the LAST of ~200k
-        // concurrently running items ends, i.e. after the maximum (not the mean) item duration, and path
-        // lengths are heavy-tailed (up to max_depth+1 vertices), so the final items must be short.
-        std::vector<int> tail;
-        if (spp >= 64) {
-            // smallest tail item: 8 samples.  Every item fetch is a returning atomic that stalls its wave
-            // for microseconds (about one sample's worth of work per item), so below 8 samples the fetches
-            // cost more than the shorter drain saves (measured on N=1..8 tile shares at spp 500).
-            int tail_min = 8;
-            if (const char* e = std::getenv("PRT_TUNE_TAILMIN")) tail_min = std::max(1, std::atoi(e));
-            for (int sz = tail_min, n = (tail_min == 1 ? 8 : 4); sz < body && (int)tail.size() < 28; sz *= 2, n = std::max(2, n / 2))
-                for (int k = 0; k < n; ++k) tail.push_back(sz);
+        int body = 128; // largest item: beyond ~100 samples the per-item costs are already amortised
+        if (const char* e = std::getenv("PRT_TUNE_BODY")) body = std::max(1, std::atoi(e));
+        double var = 3.0;
+        if (const char* e = std::getenv("PRT_TUNE_VAR")) var = std::max(0.25, std::atof(e));
+        double c = ((double)P.items_per_chunk / (double)lanes) / var;
+        for (;;) {
+            sizes.clear();
+            int64_t sum = 0;
+            while (sum < spp && (int)sizes.size() <= PRT_MAX_CHUNKS) {
+                int64_t sz = (int64_t)std::floor(c * (double)sum);
+                sz = std::max<int64_t>(1, std::min<int64_t>(sz, body));
+                sz = std::min<int64_t>(sz, spp - sum);
+                sizes.push_back((int)sz);
+                sum += sz;
+            }
+            if ((int)sizes.size() <= PRT_MAX_CHUNKS) break;
+            c *= 1.25; // a tiny share would need more chunks than the partial-sum table holds: steepen the tail
         }
-        int tail_sum = 0;
-        for (int t : tail) tail_sum += t;
-        while (!tail.empty() && tail_sum > spp / 3) { tail_sum -= tail.back(); tail.pop_back(); }
-        left -= tail_sum;
-        const int nb = std::max(1, std::min(PRT_MAX_CHUNKS - (int)tail.size(), (left + body - 1) / body));
-        for (int c = 0; c < nb; ++c) sizes.push_back((int)(((int64_t)(c + 1) * left) / nb - ((int64_t)c * left) / nb));
-        for (auto it = tail.rbegin(); it != tail.rend(); ++it) sizes.push_back(*it); // largest tail chunks first
+        std::reverse(sizes.begin(), sizes.end()); // largest chunks first
     }
     sizes.erase(std::remove(sizes.begin(), sizes.end(), 0), sizes.end());
     if (sizes.empty()) sizes.push_back(spp);
@@ -542,7 +548,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     if (P.n_items) {
         const uint64_t want = (P.n_items + PRT_BLOCK - 1) / PRT_BLOCK;
         const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)s->n_cu * bpc));
-        prt::launch_render(s->d, C, P, q.d_partial, q.d_ctr, count, s->full_materials, grid, st);
+        prt::launch_render(s->d, C, P, q.d_partial, q.d_ctr, count, s->feat, grid, st);
         PRT_HIP(hipGetLastError());
     }
     PRT_HIP(hipEventRecord(q.ev1, st));

@@ -506,39 +506,42 @@ PRT_DEV d3 ct_sample_wm(const DMaterial& m, d3 w, d2 u) { // Material.h:412-435
 
 // ------------------------------------------------------------------ Material::Eval for NEE
 // Lambertian Material.h:128-130; Phong :227-248 (draws one uniform); CookTorrance :474-496.
-// FULL = false is the lean kernel permutation for scenes whose materials are only Lambertian /
-// DiffuseLight / PerfectMirror / Debug / Empty with solid colours (chosen per scene by the host):
-// Phong, CookTorrance and image textures are compiled out, which is worth a wave of occupancy.
-template <bool FULL>
+// FEAT selects the kernel permutation (chosen per scene by the host from the material table):
+// PRT_FEAT_TEX image textures, PRT_FEAT_PHONG PhoneReflectance, PRT_FEAT_CT CookTorrance.  What a scene
+// does not use is compiled out — registers, not instructions, are what the shading code costs (a
+// permutation that fits one more wave per SIMD is worth more than any instruction-level tuning).
+#define PRT_FEAT_TEX 1
+#define PRT_FEAT_PHONG 2
+#define PRT_FEAT_CT 4
+#define PRT_FEAT_ALL 7
+template <int FEAT>
 PRT_DEV d3 mat_kd(const DScene& S, const DMaterial& m, d2 uv) {
-    if (FULL && m.texture >= 0) return tex_value(S, m.texture, uv.x, uv.y);
+    if ((FEAT & PRT_FEAT_TEX) && m.texture >= 0) return tex_value(S, m.texture, uv.x, uv.y);
     return ld3(m.kd);
 }
-template <bool FULL>
+template <int FEAT>
 PRT_DEV d3 mat_ks(const DScene& S, const DMaterial& m, d2 uv) { // Phong(mapKd,...) stores the map in Ks too (:178-181)
-    if (FULL && m.texture >= 0) return tex_value(S, m.texture, uv.x, uv.y);
+    if ((FEAT & PRT_FEAT_TEX) && m.texture >= 0) return tex_value(S, m.texture, uv.x, uv.y);
     return ld3(m.ks);
 }
-template <bool FULL>
+template <int FEAT>
 PRT_DEV d3 mat_eval(const DScene& S, const DMaterial& m, d3 wi, d3 wo, d2 uv, Rng& rng) {
-    if (!FULL) return m.type == 0 ? ld3(m.kd) * PRT_INV_PI : mk3(0, 0, 0);
-    switch (m.type) {
-    case 0: return mat_kd<FULL>(S, m, uv) * PRT_INV_PI;
-    case 1: {
+    if (m.type == 0) return mat_kd<FEAT>(S, m, uv) * PRT_INV_PI;
+    if ((FEAT & PRT_FEAT_PHONG) && m.type == 1) {
         double u = rng.next();
         if (u < m.pkd) {
             if (wi.z <= 0) return mk3(0, 0, 0);
-            return mat_kd<FULL>(S, m, uv) * PRT_INV_PI;
+            return mat_kd<FEAT>(S, m, uv) * PRT_INV_PI;
         } else if (m.pkd <= u && u < m.pkd + m.pks) {
             if (wi.z <= 0) return mk3(0, 0, 0);
             d3 lr = normalize(reflect_z(wo));
             double ca = fmax(0., dot(wi, lr));
             if (ca <= 0.) return mk3(0, 0, 0);
-            return mat_ks<FULL>(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pow_pos(ca, m.ns);
+            return mat_ks<FEAT>(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pow_pos(ca, m.ns);
         }
         return mk3(0, 0, 0);
     }
-    case 3: {
+    if ((FEAT & PRT_FEAT_CT) && m.type == 3) {
         if (!(wo.z * wi.z > 0)) return mk3(0, 0, 0);
         double co = fabs(wo.z), ci = fabs(wi.z);
         if (ci == 0 || co == 0) return mk3(0, 0, 0);
@@ -548,23 +551,23 @@ PRT_DEV d3 mat_eval(const DScene& S, const DMaterial& m, d3 wi, d3 wo, d2 uv, Rn
         d3 F = ct_fresnel(m, wo, wm);
         return ct_D(m, wm) * F * ct_G(m, wo, wi) / (4 * ci * co);
     }
-    default: return mk3(0, 0, 0);
-    }
+    return mk3(0, 0, 0);
 }
 
 // ------------------------------------------------------------------ Material::Scatter
 // Returns false when the reference's Scatter returns false.  `wi_world` is the (normalised) scattered
 // direction, `att` = f * cos / pdf.  rd = incoming ray direction (unnormalised for camera rays).
-template <bool FULL>
+template <int FEAT>
 PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame& f, d2 uv, Rng& rng, d3& att,
                          d3& wi_world) {
-    if (!FULL && m.type != 0 && m.type != 2) return false;
+    if (!(FEAT & PRT_FEAT_PHONG) && m.type == 1) return false; // not reachable: the host picks a permutation that
+    if (!(FEAT & PRT_FEAT_CT) && m.type == 3) return false;    // covers every material type of the scene
     switch (m.type) {
     case 0: { // Lambertian, Material.h:106-151
         d3 wi = cosine_hemisphere(rng);
         while (wi.z <= 0.) wi = cosine_hemisphere(rng);
         double pdf = wi.z * PRT_INV_PI;
-        d3 fr = mat_kd<FULL>(S, m, uv) * PRT_INV_PI;
+        d3 fr = mat_kd<FEAT>(S, m, uv) * PRT_INV_PI;
         wi_world = local_to_world(wi, f);
         att = (fr * wi.z) * (1.0 / pdf); // fr*cos/pdf with one reciprocal (last-bit rounding only)
         return true;
@@ -578,7 +581,7 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
             wi = cosine_hemisphere(rng);
             while (wi.z <= 0.) wi = cosine_hemisphere(rng);
             pdf = wi.z * PRT_INV_PI;
-            fr = mat_kd<FULL>(S, m, uv) * PRT_INV_PI;
+            fr = mat_kd<FEAT>(S, m, uv) * PRT_INV_PI;
         } else if (m.pkd <= u && u < m.pkd + m.pks) {
             double u1 = rng.next(), u2 = rng.next();
             double alpha = acos(pow_pos(u1, 1.0 / (m.ns + 1.0)));
@@ -597,7 +600,7 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
             if (wi.z <= 0.) pdf = 0.0;
             else pdf = (m.ns + 1.0) * PRT_INV_2PI * pow_pos(dot(wi, lr), m.ns);
             double lca = fmax(0.0, dot(wi, lr));
-            if (wi.z > 0. && lca > 0.) fr = mat_ks<FULL>(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pow_pos(lca, m.ns);
+            if (wi.z > 0. && lca > 0.) fr = mat_ks<FEAT>(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pow_pos(lca, m.ns);
         }
         wi_world = local_to_world(wi, f);
         if (pdf > 0. && wi.z > 0) att = fr * wi.z / pdf;

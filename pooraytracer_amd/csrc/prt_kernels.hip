@@ -33,6 +33,18 @@
 #ifndef PRT_RENDER_WAVES_LEAN
 #define PRT_RENDER_WAVES_LEAN 3 // the lean material permutation fits one more wave per SIMD
 #endif
+#ifndef PRT_RENDER_WAVES_TEX
+#define PRT_RENDER_WAVES_TEX 3  // Lambertian / mirror / light + image textures (bathroom2-class scenes)
+#endif
+#ifndef PRT_RENDER_WAVES_PHONG
+#define PRT_RENDER_WAVES_PHONG 2 // PhoneReflectance without textures (veach-mis-class scenes)
+#endif
+constexpr int render_waves(int feat) {
+    return feat == 0 ? PRT_RENDER_WAVES_LEAN
+         : feat == PRT_FEAT_TEX ? PRT_RENDER_WAVES_TEX
+         : feat == PRT_FEAT_PHONG ? PRT_RENDER_WAVES_PHONG
+         : PRT_RENDER_WAVES;
+}
 // The stepping loop of a wave runs while MORE than this many lanes are still traversing; below it the
 // finished lanes are handed new rays (K1) / shaded and re-armed (K3).
 #ifndef PRT_K1_KEEP
@@ -58,6 +70,17 @@ namespace {
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+#ifndef PRT_K3_TIMING
+#define PRT_K3_TIMING 0
+#endif
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
     return v;
 }
 
@@ -161,7 +184,7 @@ struct ShadeCtx {
     d2 uv;
     int32_t material;
 };
-template <bool FULL>
+template <int FEAT>
 PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 ro, d3 rd, const HitInfo& h) {
     ShadeCtx c;
     const DTriShade* sh = S.shade + h.tri;
@@ -171,7 +194,7 @@ PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 ro, d3 rd, const HitInfo& h) {
     c.f.n = front ? gn : -gn;
     c.f.t = ld3(sh->tangent);
     c.pos = ro + rd * h.t;
-    if (FULL) { // texture coordinates are only read by image-textured materials
+    if (FEAT & PRT_FEAT_TEX) { // texture coordinates are only read by image-textured materials
         const double w0 = 1. - h.alpha - h.beta;
         c.uv.x = w0 * sh->uv0[0] + h.alpha * sh->uv1[0] + h.beta * sh->uv2[0];
         c.uv.y = w0 * sh->uv0[1] + h.alpha * sh->uv1[1] + h.beta * sh->uv2[1];
@@ -182,8 +205,8 @@ PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 ro, d3 rd, const HitInfo& h) {
     return c;
 }
 
-template <bool COUNT, bool FULL>
-__global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WAVES_LEAN)) void k_render(
+template <bool COUNT, int FEAT>
+__global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     DScene S, DCamera C, DRenderParams P, double* __restrict__ partial, DCounters* ctr) {
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
     __shared__ unsigned long long s_pool[PRT_BLOCK / 64][2];
@@ -203,6 +226,12 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
 
     WorkCount wc{0, 0, 0, 0};
     uint32_t n_closest = 0, n_shadow = 0, n_samples = 0, n_refills = 0;
+#if PRT_K3_TIMING
+    // developer diagnostic (COUNT instantiation only): 100 MHz timestamps of this wave's start, of the first
+    // failed item fetch and of its end are folded into inner_rounds / leaf_rounds / refills / tri_tests
+    const unsigned long long tm_start = wall_clock64();
+    unsigned long long tm_dry = 0;
+#endif
 
     int state = ST_FETCH;
     uint64_t item = 0;
@@ -285,7 +314,7 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
                     sh.alpha = sh_alpha;
                     sh.beta = sh_beta;
                     sh.tri = sh_tri;
-                    const ShadeCtx c = make_ctx<FULL>(S, to, rd, sh);
+                    const ShadeCtx c = make_ctx<FEAT>(S, to, rd, sh);
                     const DMaterial& m = S.materials[c.material];
                     const DLightTri* lt = S.light_tris + ltri;
                     const d3 ln0 = ld3(lt->n);
@@ -296,7 +325,7 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
                     const d3 wo = world_to_local(-rd, c.f);
                     const d3 lwi = world_to_local(td, c.f);
                     const d3 lln = world_to_local(ln, c.f);
-                    const d3 fr = mat_eval<FULL>(S, m, lwi, wo, c.uv, rng);
+                    const d3 fr = mat_eval<FEAT>(S, m, lwi, wo, c.uv, rng);
                     const double cosT = lwi.z;
                     const double cosTB = dot(lln, -lwi);
                     // Camera.cpp:172: emission*fr*cosT*cosTB/dist^2/pdf, the scalar factor folded into one division
@@ -315,10 +344,10 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
                     sh.alpha = sh_alpha;
                     sh.beta = sh_beta;
                     sh.tri = sh_tri;
-                    const ShadeCtx c = make_ctx<FULL>(S, pos, rd, sh);
+                    const ShadeCtx c = make_ctx<FEAT>(S, pos, rd, sh);
                     const DMaterial& m = S.materials[c.material];
                     d3 att, wi;
-                    if (mat_scatter<FULL>(S, m, rd, c.f, c.uv, rng, att, wi)) {
+                    if (mat_scatter<FEAT>(S, m, rd, c.f, c.uv, rng, att, wi)) {
                         depth--; // RayColor(scattered, depth-1): returns 0 when depth-1 < 0
                         if (depth >= 0) {
                             const d3 beta = (PST_LD(S_BETA) * att) * P.inv_rr;
@@ -389,6 +418,9 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
 #endif
                 if (item >= P.n_items) {
                     state = ST_DONE;
+#if PRT_K3_TIMING
+                    if (COUNT && tm_dry == 0) tm_dry = wall_clock64();
+#endif
                 } else {
                     const uint32_t chunk = (uint32_t)(item / P.items_per_chunk);
                     const uint64_t oi = item % P.items_per_chunk;
@@ -453,12 +485,25 @@ __global__ __launch_bounds__(PRT_BLOCK, (FULL ? PRT_RENDER_WAVES : PRT_RENDER_WA
         atomicAdd(&ctr->samples, c);
         if (COUNT) {
             atomicAdd(&ctr->node_fetches, d);
+#if PRT_K3_TIMING
+            const unsigned long long tm_end = wall_clock64();
+            atomicMax(&ctr->inner_rounds, ~tm_start);               // -> earliest wave start
+            atomicMax(&ctr->refills, tm_end);                      // -> latest wave end
+            atomicAdd(&ctr->tri_tests, tm_end - tm_start);         // -> sum of wave lifetimes
+#else
             atomicAdd(&ctr->tri_tests, e);
             atomicAdd(&ctr->inner_rounds, (unsigned long long)wc.inner_rounds);
             atomicAdd(&ctr->leaf_rounds, (unsigned long long)wc.leaf_rounds);
             atomicAdd(&ctr->refills, (unsigned long long)n_refills);
+#endif
         }
     }
+#if PRT_K3_TIMING
+    if (COUNT) {
+        unsigned long long dry = wave_max_u64(tm_dry ? ~tm_dry : 0ULL); // earliest dry fetch within the wave
+        if (lane == 0 && dry) atomicMax(&ctr->leaf_rounds, dry);      // -> earliest dry fetch of the launch
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------- K5
@@ -523,13 +568,26 @@ __global__ void k_tonemap(const float* __restrict__ in, size_t n, uint8_t* __res
 // ------------------------------------------------------------------------------------------- launchers
 namespace prt {
 
-int render_blocks_per_cu(bool count, bool full) {
+// The compiled permutations: lean, textures only, Phong only, everything.  A scene gets the smallest one
+// that covers its materials.
+int render_permutation(int feat) {
+    if (feat == 0 || feat == PRT_FEAT_TEX || feat == PRT_FEAT_PHONG) return feat;
+    return PRT_FEAT_ALL;
+}
+
+typedef void (*RenderKernel)(DScene, DCamera, DRenderParams, double*, DCounters*);
+static RenderKernel render_kernel(bool count, int feat) {
+    switch (render_permutation(feat)) {
+    case 0: return count ? k_render<true, 0> : k_render<false, 0>;
+    case PRT_FEAT_TEX: return count ? k_render<true, PRT_FEAT_TEX> : k_render<false, PRT_FEAT_TEX>;
+    case PRT_FEAT_PHONG: return count ? k_render<true, PRT_FEAT_PHONG> : k_render<false, PRT_FEAT_PHONG>;
+    default: return count ? k_render<true, PRT_FEAT_ALL> : k_render<false, PRT_FEAT_ALL>;
+    }
+}
+
+int render_blocks_per_cu(bool count, int feat) {
     int nb = 0;
-    hipError_t e;
-    if (count) e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render<true, true>, PRT_BLOCK, 0)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render<true, false>, PRT_BLOCK, 0);
-    else e = full ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render<false, true>, PRT_BLOCK, 0)
-                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_render<false, false>, PRT_BLOCK, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel(count, feat), PRT_BLOCK, 0);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
@@ -544,12 +602,8 @@ void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hit
 }
 
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
-                   bool count, bool full, unsigned grid, hipStream_t st) {
-    const dim3 g(grid), b(PRT_BLOCK);
-    if (count && full) hipLaunchKernelGGL((k_render<true, true>), g, b, 0, st, S, C, P, d_partial, d_ctr);
-    else if (count) hipLaunchKernelGGL((k_render<true, false>), g, b, 0, st, S, C, P, d_partial, d_ctr);
-    else if (full) hipLaunchKernelGGL((k_render<false, true>), g, b, 0, st, S, C, P, d_partial, d_ctr);
-    else hipLaunchKernelGGL((k_render<false, false>), g, b, 0, st, S, C, P, d_partial, d_ctr);
+                   bool count, int feat, unsigned grid, hipStream_t st) {
+    hipLaunchKernelGGL(render_kernel(count, feat), dim3(grid), dim3(PRT_BLOCK), 0, st, S, C, P, d_partial, d_ctr);
 }
 
 void launch_finalize(const DCamera& C, const DRenderParams& P, const double* d_partial, double* d64, float* d32,

@@ -42,12 +42,13 @@ struct Hittable::DeviceCache {
     ~DeviceCache() {
         if (scene) prt_scene_destroy(scene);
     }
-    void Ensure(const Hittable& h, int dev) {
+    void Ensure(const Hittable& h, int dev, unsigned flags = 0) {
         if (!scene) {
             h.Flatten(flat);
             flat.EndMesh();
             PrtSceneDesc d;
             flat.Describe(d);
+            d.flags = flags;
             check(prt_scene_create(&d, &scene), "prt_scene_create");
         }
         if (device != dev) {
@@ -272,7 +273,7 @@ void Camera::Render(Hittable& world, Hittable& lights) {
     imageWidth = (imageWidth < 1) ? 1 : imageWidth; // Camera.cpp:77-78
     imageHeight = (imageHeight < 1) ? 1 : imageHeight;
     Hittable::DeviceCache& dc = world.Device();
-    dc.Ensure(world, device);
+    dc.Ensure(world, device, bBuildBvhOnDevice ? PRT_SCENE_DEVICE_BVH : 0u);
     // The library derives the NEE light set from the emissive meshes of `world` in mesh order, exactly
     // as main.cpp:36-45 builds `lights`; a caller-supplied list that disagrees is reported, not used.
     {
