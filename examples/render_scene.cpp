@@ -9,6 +9,7 @@
 // usage: render_scene <scene.bin> <spp> <depth> <out.f64> [out.png] [camera.xml]
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -57,6 +58,15 @@ int main(int argc, char** argv) {
         camera.lookAt = vec3(v[3], v[4], v[5]);
         camera.up = vec3(v[6], v[7], v[8]);
         if (argc > 6) camera.SetViewParametersByXmlFile(argv[6]);
+        // additions of this build, driven from the environment so the argument list stays main.cpp-like
+        if (const char* e = std::getenv("PRT_EXAMPLE_DEVICES")) { // e.g. "0,1,2,3": tiles over several GPUs
+            for (const char* q = e; *q;) {
+                camera.devices.push_back(std::atoi(q));
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+        }
+        if (const char* e = std::getenv("PRT_EXAMPLE_DEVICE_BVH")) camera.bBuildBvhOnDevice = std::atoi(e) != 0;
 
         const uint32_t nTex = rd<uint32_t>(f);
         std::vector<std::shared_ptr<Texture>> textures;

@@ -39,6 +39,7 @@ public:
     bool bBuildBvhOnDevice = false; // PRT_SCENE_DEVICE_BVH: build the traversal BVH on the GPU (first Render of a world)
     bool bPixelJitter = false; // per-sample SampleSquare() pixel offset: the AA the reference has commented out (Camera.cpp:110-111)
     int device = 0;
+    std::vector<int> devices; // non-empty: cut the frame into tiles over these GPUs (one host thread each); overrides `device`
     unsigned long long lastRays = 0;
     double lastKernelMs = 0.0;
 };

@@ -50,7 +50,7 @@ def build_host_example(force=False):
     if fresh and not force:
         return HOST_EXE
     build()
-    common = ["-O2", "-std=c++17", "-Wall", "-I", inc, "-L", HERE, "-Wl,-rpath,$ORIGIN"]
+    common = ["-O2", "-std=c++17", "-Wall", "-pthread", "-I", inc, "-L", HERE, "-Wl,-rpath,$ORIGIN"]
     subprocess.check_call(["g++", "-shared", "-fPIC"] + common + ["-o", HOST_LIB] + srcs + ["-lprt_hip"])
     subprocess.check_call(["g++"] + common + ["-o", HOST_EXE, exe_src, "-lpooraytracer_host", "-lprt_hip"])
     subprocess.check_call(["g++"] + common + ["-o", MAIN_EXE, main_src, "-lpooraytracer_host", "-lprt_hip"])

@@ -8,6 +8,9 @@
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "pooraytracer/BVH.h"
 #include "pooraytracer/Camera.h"
@@ -41,6 +44,34 @@ struct Hittable::DeviceCache {
     unsigned long long sampleCounter = 0;
     ~DeviceCache() {
         if (scene) prt_scene_destroy(scene);
+        for (Replica& r : replicas)
+            if (r.scene) prt_scene_destroy(r.scene);
+    }
+    // Additional replicas of the scene for Camera::devices (one PrtScene per extra GPU).
+    struct Replica {
+        PrtScene* scene = nullptr;
+        int device = -1;
+    };
+    std::vector<Replica> replicas;
+    void EnsureReplicas(const std::vector<int>& devs, unsigned flags) { // devs[0] is served by `scene`
+        while (replicas.size() + 1 > devs.size()) {
+            if (replicas.back().scene) prt_scene_destroy(replicas.back().scene);
+            replicas.pop_back();
+        }
+        replicas.resize(devs.size() - 1);
+        for (size_t i = 0; i < replicas.size(); ++i) {
+            Replica& r = replicas[i];
+            if (!r.scene) {
+                PrtSceneDesc d;
+                flat.Describe(d);
+                d.flags = flags;
+                check(prt_scene_create(&d, &r.scene), "prt_scene_create");
+            }
+            if (r.device != devs[i + 1]) {
+                check(prt_scene_upload(r.scene, devs[i + 1]), "prt_scene_upload");
+                r.device = devs[i + 1];
+            }
+        }
     }
     void Ensure(const Hittable& h, int dev, unsigned flags = 0) {
         if (!scene) {
@@ -273,7 +304,10 @@ void Camera::Render(Hittable& world, Hittable& lights) {
     imageWidth = (imageWidth < 1) ? 1 : imageWidth; // Camera.cpp:77-78
     imageHeight = (imageHeight < 1) ? 1 : imageHeight;
     Hittable::DeviceCache& dc = world.Device();
-    dc.Ensure(world, device, bBuildBvhOnDevice ? PRT_SCENE_DEVICE_BVH : 0u);
+    const unsigned sceneFlags = bBuildBvhOnDevice ? PRT_SCENE_DEVICE_BVH : 0u;
+    const std::vector<int> devs = devices.empty() ? std::vector<int>{device} : devices;
+    dc.Ensure(world, devs[0], sceneFlags);
+    dc.EnsureReplicas(devs, sceneFlags);
     // The library derives the NEE light set from the emissive meshes of `world` in mesh order, exactly
     // as main.cpp:36-45 builds `lights`; a caller-supplied list that disagrees is reported, not used.
     {
@@ -305,14 +339,42 @@ void Camera::Render(Hittable& world, Hittable& lights) {
     p.nranks = 1;
     p.pixel_jitter = bPixelJitter ? 1 : 0;
     std::vector<double> rgb((size_t)imageWidth * imageHeight * 3);
-    check(prt_render(dc.scene, &c, &p, rgb.data(), nullptr), "prt_render");
+    if (devs.size() == 1) {
+        check(prt_render(dc.scene, &c, &p, rgb.data(), nullptr), "prt_render");
+    } else {
+        // One host thread per GPU, 16x16 tiles dealt over the devices exactly as bench.py deals them over
+        // ranks; every device leaves the other devices' tiles at 0, so adding the buffers is exact and the
+        // image equals the single-GPU one bit for bit (the per-sample RNG is keyed on the global pixel).
+        const int n = (int)devs.size();
+        std::vector<std::vector<double>> part(n - 1, std::vector<double>(rgb.size()));
+        std::vector<std::string> errors(n);
+        std::vector<std::thread> workers;
+        for (int r = 0; r < n; ++r)
+            workers.emplace_back([&, r] {
+                PrtRenderParams pr = p;
+                pr.tile_size = 16;
+                pr.rank = r;
+                pr.nranks = n;
+                PrtScene* sc = r == 0 ? dc.scene : dc.replicas[r - 1].scene;
+                double* out = r == 0 ? rgb.data() : part[r - 1].data();
+                if (prt_render(sc, &c, &pr, out, nullptr) != PRT_OK) errors[r] = prt_last_error();
+            });
+        for (auto& w : workers) w.join();
+        for (int r = 0; r < n; ++r)
+            if (!errors[r].empty()) throw std::runtime_error("prt_render (device " + std::to_string(devs[r]) + "): " + errors[r]);
+        for (const auto& pbuf : part)
+            for (size_t i = 0; i < rgb.size(); ++i) rgb[i] += pbuf[i];
+    }
     colorAttachment.assign((size_t)imageWidth * imageHeight, color(0., 0., 0.)); // cleared every frame
     for (size_t i = 0; i < colorAttachment.size(); ++i) colorAttachment[i] = color(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
     PrtCounters cnt;
-    if (prt_get_counters(dc.scene, &cnt) == PRT_OK) {
-        lastRays = cnt.rays_closest + cnt.rays_shadow;
-        lastKernelMs = cnt.kernel_ms;
-    }
+    lastRays = 0;
+    lastKernelMs = 0.0;
+    for (size_t r = 0; r < devs.size(); ++r)
+        if (prt_get_counters(r == 0 ? dc.scene : dc.replicas[r - 1].scene, &cnt) == PRT_OK) {
+            lastRays += cnt.rays_closest + cnt.rays_shadow;
+            lastKernelMs = std::max(lastKernelMs, cnt.kernel_ms); // the devices run concurrently
+        }
 }
 
 std::string Camera::GetParametersStr() const { // Camera.cpp:332-337

@@ -39,6 +39,26 @@ def test_render_scene_driver_matches_binding_and_oracle(gpu, tmp_path):
     assert os.path.getsize(hdr) > 32 * 40 * 4
 
 
+def test_camera_devices_and_device_bvh(gpu, tmp_path):
+    """Camera::devices cuts the frame into tiles over several scene replicas (here all on the one GPU of the
+    box, one host thread each) and sums the buffers: the image must equal the single-device one bit for bit.
+    Camera::bBuildBvhOnDevice (GPU-built BVH) must not change the image either."""
+    exe = build.build_host_example()
+    data = scenes.mixed_materials(56, 40)
+    dump = str(tmp_path / "scene.bin")
+    scenes.dump_scene(data, dump)
+    outs = {}
+    for tag, env in (("one", {}), ("three", {"PRT_EXAMPLE_DEVICES": f"{gpu},{gpu},{gpu}"}),
+                     ("gpubvh", {"PRT_EXAMPLE_DEVICE_BVH": "1"})):
+        out = str(tmp_path / f"{tag}.f64")
+        r = subprocess.run([exe, dump, "5", "6", out], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr + r.stdout
+        outs[tag] = np.fromfile(out, dtype=np.float64)
+    assert np.array_equal(outs["one"], outs["three"])
+    assert np.array_equal(outs["one"], outs["gpubvh"])
+
+
 def test_camera_xml_override(gpu, tmp_path):
     exe = build.build_host_example()
     data = scenes.tiny_scene()
