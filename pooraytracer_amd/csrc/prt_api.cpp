@@ -504,6 +504,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     } else {
         int body = 128; // largest item: beyond ~100 samples the per-item costs are already amortised
         if (const char* e = std::getenv("PRT_TUNE_BODY")) body = std::max(1, std::atoi(e));
+        body = std::max(body, (spp + PRT_MAX_CHUNKS / 2 - 1) / (PRT_MAX_CHUNKS / 2)); // very high spp: the body must fit in half the table
         double var = 3.0;
         if (const char* e = std::getenv("PRT_TUNE_VAR")) var = std::max(0.25, std::atof(e));
         double c = ((double)P.items_per_chunk / (double)lanes) / var;
@@ -519,6 +520,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
             }
             if ((int)sizes.size() <= PRT_MAX_CHUNKS) break;
             c *= 1.25; // a tiny share would need more chunks than the partial-sum table holds: steepen the tail
+            if (c > 1e9) body *= 2; // (cannot happen with the body bound above; keeps the loop finite regardless)
         }
         std::reverse(sizes.begin(), sizes.end()); // largest chunks first
     }

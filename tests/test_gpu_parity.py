@@ -173,6 +173,13 @@ def test_render_options(gpu):
     assert np.allclose(a, b, rtol=1e-13, atol=1e-15)
     # determinism: bitwise identical across runs
     assert np.array_equal(b, sc.render(spp=16, max_depth=6, sample_chunks=4))
+    # the automatic item schedule (a share-dependent geometric tail, <= 64 chunks) covers every sample exactly
+    # once at any spp: very high spp on few pixels, tile shares that leave a rank a single tile, spp = 1
+    small = scenes.Camera(24, 16, data.camera.fovy, data.camera.eye, data.camera.look_at)
+    for kw in (dict(spp=4100, max_depth=1), dict(spp=333, max_depth=2, rank=1, nranks=3, tile_size=8), dict(spp=1, max_depth=3)):
+        one = sc.render(camera=small, sample_chunks=1, **kw)
+        auto = sc.render(camera=small, **kw)
+        assert np.allclose(auto, one, rtol=1e-12, atol=1e-15), kw
 
 
 def test_tile_sharding_sums_to_full_image(gpu):
