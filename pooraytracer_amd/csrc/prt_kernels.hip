@@ -217,12 +217,15 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
         pool[0] = 0;
         pool[1] = 0;
     }
-    d3 pst_[3]; // acc, L (radiance of the current sample), beta (path throughput)
+    d3 pst_[2]; // acc (this item's sum of sample radiance / spp), beta (path throughput)
 #define PST_LD(k) (pst_[(k) / 3])
 #define PST_ST(k, v) (pst_[(k) / 3] = (v))
 #define S_ACC 0
-#define S_L 3
-#define S_BETA 6
+#define S_BETA 3
+// A radiance term x met by the current path (emission, background, NEE): colorAttachment[m] += RayColor(...) *
+// pixelSamplesScale (Camera.cpp:56) with RayColor unrolled into sum_k beta_k * x_k; each term is scaled and
+// added on the spot, so no per-sample radiance has to live in registers across traversals.
+#define ADD_RADIANCE(x) PST_ST(S_ACC, PST_LD(S_ACC) + (PST_LD(S_BETA) * (x)) * inv_spp)
 
     WorkCount wc{0, 0, 0, 0};
     uint32_t n_closest = 0, n_shadow = 0, n_samples = 0, n_refills = 0;
@@ -238,7 +241,6 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     int px = 0, py = 0, s = 0, s_end = 0, depth = 0;
     bool first = true, prev_skip = false;
     PST_ST(S_ACC, mk3(0, 0, 0));  // sum over this item's samples of colour * (1/spp)
-    PST_ST(S_L, mk3(0, 0, 0));    // radiance of the current sample
     PST_ST(S_BETA, mk3(1, 1, 1)); // path throughput
     // Across a continuation traversal the ray lives in tr.o / tr.d only.  Across a shadow traversal
     // tr.o is the shading point itself, so only the incoming direction, the hit's barycentrics and
@@ -268,13 +270,13 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 const HitInfo h = tr.hit;
                 if (h.tri < 0) {
                     // miss: background for the camera ray (Camera.cpp:127); with bSampleLights a bounce miss adds 0 (:187)
-                    if (first || !P.sample_lights) PST_ST(S_L, PST_LD(S_L) + PST_LD(S_BETA) * ld3(P.background));
+                    if (first || !P.sample_lights) ADD_RADIANCE(ld3(P.background));
                     end_sample = true;
                 } else {
                     const DMaterial& m = S.materials[S.shade[h.tri].material];
                     if (m.has_emission) {
                         // Camera.cpp:129-132; via a bounce only after SkipLightSampling materials (:191-195)
-                        if (first || !P.sample_lights || prev_skip) PST_ST(S_L, PST_LD(S_L) + PST_LD(S_BETA) * ld3(m.emission));
+                        if (first || !P.sample_lights || prev_skip) ADD_RADIANCE(ld3(m.emission));
                         end_sample = true;
                     } else {
                         rd = tr.d;
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     const double cosTB = dot(lln, -lwi);
                     // Camera.cpp:172: emission*fr*cosT*cosTB/dist^2/pdf, the scalar factor folded into one division
                     const d3 direct = (emission * fr) * (cosT * cosTB / ((dist * dist) * pdf));
-                    PST_ST(S_L, PST_LD(S_L) + PST_LD(S_BETA) * direct);
+                    ADD_RADIANCE(direct);
                 }
                 state = ST_CLOSEST;
                 do_scatter = true;
@@ -365,8 +367,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 }
             }
             if (end_sample) {
-                const d3 acc = PST_LD(S_ACC) + PST_LD(S_L) * inv_spp; // colorAttachment[m] += RayColor(...) * pixelSamplesScale (Camera.cpp:56)
-                PST_ST(S_ACC, acc);
+                const d3 acc = PST_LD(S_ACC);
                 s++;
                 if (s < s_end) state = ST_NEW_SAMPLE;
                 else {
@@ -447,7 +448,6 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 const d3 ps = ld3(C.pixel00) + fx * ld3(C.du) + fy * ld3(C.dv);
                 next_o = ld3(C.center);
                 next_d = ps - next_o;
-                PST_ST(S_L, mk3(0, 0, 0));
                 PST_ST(S_BETA, mk3(1, 1, 1));
                 depth = P.max_depth;
                 first = true;
