@@ -183,6 +183,12 @@ void prt_scene_destroy(PrtScene* scene);
 /* Build + flatten the BVH on the host and upload SoA nodes / triangles / materials / light tree. */
 int prt_scene_upload(PrtScene* scene, int device);
 
+/* New vertex positions ([n_tris][3][xyz], same layout as PrtSceneDesc.vertices; normals may be NULL) for a
+ * scene whose topology, materials and texture coordinates stay as created: re-runs the Triangle constructor
+ * precompute and the light tree; on an uploaded scene the BVH is REBUILT on the GPU (PRT_SCENE_DEVICE_BVH
+ * path: 4 ms per 126k triangles, 17 ms per 8M), which is what a refit would be for, without its quality decay. */
+int prt_scene_update_vertices(PrtScene* scene, const double* vertices, const double* normals);
+
 /* Number of light triangles and their order in the reference's area-CDF descent (BVH.cpp:86-100). */
 int prt_scene_bvh_info(const PrtScene* scene, PrtBvhInfo* out);
 

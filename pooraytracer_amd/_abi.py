@@ -171,6 +171,7 @@ EXPORTS = [
     "prt_scene_create",
     "prt_scene_destroy",
     "prt_scene_upload",
+    "prt_scene_update_vertices",
     "prt_scene_bvh_info",
     "prt_scene_light_count",
     "prt_scene_light_order",

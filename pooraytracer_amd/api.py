@@ -50,6 +50,7 @@ def load():
     L.prt_scene_destroy.restype = None
     L.prt_scene_upload.argtypes = [vp, i32]
     L.prt_scene_bvh_info.argtypes = [vp, vp]
+    L.prt_scene_update_vertices.argtypes = [vp, vp, vp]
     L.prt_scene_light_count.argtypes = [vp, C.POINTER(u64)]
     L.prt_scene_light_order.argtypes = [vp, vp, u64]
     L.prt_trace_closest.argtypes = [vp, vp, sz, vp, i32]
@@ -105,6 +106,14 @@ class Scene:
     def upload(self, device=0):
         _check(load().prt_scene_upload(self._h, device))
         self.device = device
+        return self
+
+    def update_vertices(self, vertices, normals=None):
+        """New positions for the same triangles; an uploaded scene rebuilds its BVH on the GPU."""
+        v = np.ascontiguousarray(vertices, dtype=np.float64)
+        assert v.shape == self.data.vertices.shape
+        n = None if normals is None else np.ascontiguousarray(normals, dtype=np.float64)
+        _check(load().prt_scene_update_vertices(self._h, v.ctypes.data, None if n is None else n.ctypes.data))
         return self
 
     def bvh_info(self):

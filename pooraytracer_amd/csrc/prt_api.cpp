@@ -55,6 +55,8 @@ struct PrtScene {
     std::vector<double> texels_lin; // GetPixel() of every texel (Texture.cpp:50-65)
     prt::LightTree lights;
     prt::BuiltBVH bvh;
+    std::vector<uint64_t> mesh_first; // mesh structure, kept for prt_scene_update_vertices
+    std::vector<int32_t> mesh_mat;
     bool device_bvh = false; // PRT_SCENE_DEVICE_BVH: the tree is built in prt_scene_upload, on the GPU
     PrtBvhInfo bvh_info{};
     // device side
@@ -151,6 +153,8 @@ int prt_scene_create(const PrtSceneDesc* desc, PrtScene** out) {
     if (!s) return fail(PRT_E_OOM, "prt_scene_create: out of host memory");
     try {
         prt::setup_triangles(*desc, s->tris);
+        s->mesh_first.assign(desc->mesh_first_tri, desc->mesh_first_tri + (desc->n_meshes ? desc->n_meshes + 1 : 0));
+        s->mesh_mat.assign(desc->mesh_material, desc->mesh_material + desc->n_meshes);
         prt::setup_materials(*desc, s->mats);
         s->texs.resize(desc->n_textures);
         for (uint32_t i = 0; i < desc->n_textures; ++i) {
@@ -358,6 +362,36 @@ int prt_scene_upload(PrtScene* s, int device) {
     s->feat = prt::render_permutation(s->feat);
     s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat);
     s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat);
+    return PRT_OK;
+}
+
+int prt_scene_update_vertices(PrtScene* s, const double* vertices, const double* normals) {
+    if (!s || (!vertices && !s->tris.empty())) return fail(PRT_E_INVALID, "prt_scene_update_vertices: null argument");
+    try {
+        prt::update_triangles(vertices, normals, s->tris);
+        PrtSceneDesc d;
+        std::memset(&d, 0, sizeof(d));
+        d.n_tris = s->tris.size();
+        d.n_meshes = (uint32_t)s->mesh_mat.size();
+        d.mesh_first_tri = s->mesh_first.data();
+        d.mesh_material = s->mesh_mat.data();
+        s->lights = prt::LightTree();
+        prt::build_light_tree(d, s->tris, s->mats, s->lights); // light areas and the CDF order follow the geometry
+        if (s->device >= 0 && s->tris.size() >= 2) {
+            // moving geometry: the tree is rebuilt on the GPU (milliseconds; no refit needed, no quality decay)
+            s->device_bvh = true;
+        } else if (!s->device_bvh) {
+            std::string err;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (!prt::build_bvh(s->tris, s->bvh, &err)) return fail(PRT_E_LIMIT, "prt_scene_update_vertices: " + err);
+            s->bvh_info.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            s->last.bvh_nodes = s->bvh_info.n_nodes = s->bvh.nodes.size();
+            s->last.bvh_depth = s->bvh_info.depth = s->bvh.depth;
+        }
+    } catch (const std::bad_alloc&) {
+        return fail(PRT_E_OOM, "prt_scene_update_vertices: out of host memory");
+    }
+    if (s->device >= 0) return prt_scene_upload(s, s->device);
     return PRT_OK;
 }
 

@@ -56,6 +56,8 @@ struct LightTree {
 
 // Triangle.cpp:11-53 for every triangle of the description.
 void setup_triangles(const PrtSceneDesc& d, std::vector<HostTri>& out);
+// Re-runs the Triangle constructor for new vertex positions (topology, materials, uv unchanged).
+void update_triangles(const double* vertices, const double* normals, std::vector<HostTri>& tris);
 // Material table incl. SetProbabilitiesByNs / HasEmission / SkipLightSampling (Material.h).
 void setup_materials(const PrtSceneDesc& d, std::vector<DMaterial>& out);
 // Binned-SAH BVH2, depth-bounded to PRT_STACK_DEPTH, child boxes rounded outward to fp32.

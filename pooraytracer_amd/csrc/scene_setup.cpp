@@ -41,6 +41,45 @@ inline void edge_interval(double a, double b, double& lo, double& hi) {
 
 } // namespace
 
+// Triangle::Triangle (Triangle.cpp:11-53) for one triangle whose vertices p[], vertex normals vn[] and T.uv are given.
+static void setup_triangle_geometry(HostTri& T, const V p[3], const V vn[3]) {
+    for (int k = 0; k < 3; ++k) store(T.v[k], p[k]);
+    V e0 = sub(p[1], p[0]), e1 = sub(p[2], p[0]);
+    V n = cross(e0, e1);
+    V nn = unit(n);
+    if (has_nan(nn)) { // degenerate face: vertex-normal fallback, then +z (Triangle.cpp:21-29)
+        nn = unit(add(add(vn[0], vn[1]), vn[2]));
+        if (has_nan(nn)) nn = V{0.0, 0.0, 1.0};
+    }
+    // tangent from the UV deltas (Triangle.cpp:31-37)
+    double du0 = T.uv[1][0] - T.uv[0][0], dv0 = T.uv[1][1] - T.uv[0][1];
+    double du1 = T.uv[2][0] - T.uv[0][0], dv1 = T.uv[2][1] - T.uv[0][1];
+    double f = 1.0 / (du0 * dv1 - du1 * dv0);
+    V tg{f * (dv1 * e0.x - dv0 * e1.x), f * (dv1 * e0.y - dv0 * e1.y), f * (dv1 * e0.z - dv0 * e1.z)};
+    tg = unit(tg);
+    if (has_nan(tg)) { // Triangle.cpp:39-46 (0.9f: float literal)
+        V helper = (std::fabs(nn.x) < (double)0.9f) ? V{1, 0, 0} : V{0, 1, 0};
+        tg = unit(cross(nn, helper));
+    }
+    store(T.e0, e0);
+    store(T.e1, e1);
+    store(T.normal, nn);
+    store(T.tangent, tg);
+    T.area = std::sqrt(dot(n, n)) * 0.5;
+    T.D = dot(nn, p[0]);
+    double nn2 = dot(n, n);
+    T.w[0] = n.x / nn2;
+    T.w[1] = n.y / nn2;
+    T.w[2] = n.z / nn2;
+    for (int a = 0; a < 3; ++a) {
+        double l0, h0, l1, h1;
+        edge_interval(T.v[0][a], T.v[1][a], l0, h0);
+        edge_interval(T.v[0][a], T.v[2][a], l1, h1);
+        T.lo[a] = l0 <= l1 ? l0 : l1;
+        T.hi[a] = h0 >= h1 ? h0 : h1;
+    }
+}
+
 void setup_triangles(const PrtSceneDesc& d, std::vector<HostTri>& out) {
     out.resize(d.n_tris);
     for (uint32_t m = 0; m < d.n_meshes; ++m) {
@@ -52,45 +91,23 @@ void setup_triangles(const PrtSceneDesc& d, std::vector<HostTri>& out) {
                 vn[k] = d.normals ? load(d.normals + t * 9 + k * 3) : V{0, 0, 0};
                 T.uv[k][0] = d.texcoords ? d.texcoords[t * 6 + k * 2] : 0.0;
                 T.uv[k][1] = d.texcoords ? d.texcoords[t * 6 + k * 2 + 1] : 0.0;
-                store(T.v[k], p[k]);
             }
             T.material = d.mesh_material[m];
             T.prim = (int32_t)t;
-            V e0 = sub(p[1], p[0]), e1 = sub(p[2], p[0]);
-            V n = cross(e0, e1);
-            V nn = unit(n);
-            if (has_nan(nn)) { // degenerate face: vertex-normal fallback, then +z (Triangle.cpp:21-29)
-                nn = unit(add(add(vn[0], vn[1]), vn[2]));
-                if (has_nan(nn)) nn = V{0.0, 0.0, 1.0};
-            }
-            // tangent from the UV deltas (Triangle.cpp:31-37)
-            double du0 = T.uv[1][0] - T.uv[0][0], dv0 = T.uv[1][1] - T.uv[0][1];
-            double du1 = T.uv[2][0] - T.uv[0][0], dv1 = T.uv[2][1] - T.uv[0][1];
-            double f = 1.0 / (du0 * dv1 - du1 * dv0);
-            V tg{f * (dv1 * e0.x - dv0 * e1.x), f * (dv1 * e0.y - dv0 * e1.y), f * (dv1 * e0.z - dv0 * e1.z)};
-            tg = unit(tg);
-            if (has_nan(tg)) { // Triangle.cpp:39-46 (0.9f: float literal)
-                V helper = (std::fabs(nn.x) < (double)0.9f) ? V{1, 0, 0} : V{0, 1, 0};
-                tg = unit(cross(nn, helper));
-            }
-            store(T.e0, e0);
-            store(T.e1, e1);
-            store(T.normal, nn);
-            store(T.tangent, tg);
-            T.area = std::sqrt(dot(n, n)) * 0.5;
-            T.D = dot(nn, p[0]);
-            double nn2 = dot(n, n);
-            T.w[0] = n.x / nn2;
-            T.w[1] = n.y / nn2;
-            T.w[2] = n.z / nn2;
-            for (int a = 0; a < 3; ++a) {
-                double l0, h0, l1, h1;
-                edge_interval(T.v[0][a], T.v[1][a], l0, h0);
-                edge_interval(T.v[0][a], T.v[2][a], l1, h1);
-                T.lo[a] = l0 <= l1 ? l0 : l1;
-                T.hi[a] = h0 >= h1 ? h0 : h1;
-            }
+            setup_triangle_geometry(T, p, vn);
         }
+    }
+}
+
+// New vertex positions for an existing triangle set (same meshes, materials and texture coordinates).
+void update_triangles(const double* vertices, const double* normals, std::vector<HostTri>& tris) {
+    for (size_t t = 0; t < tris.size(); ++t) {
+        V p[3], vn[3];
+        for (int k = 0; k < 3; ++k) {
+            p[k] = load(vertices + t * 9 + k * 3);
+            vn[k] = normals ? load(normals + t * 9 + k * 3) : V{0, 0, 0};
+        }
+        setup_triangle_geometry(tris[t], p, vn);
     }
 }
 

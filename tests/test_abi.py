@@ -59,6 +59,21 @@ def test_scene_create_and_light_order_without_gpu(prt_lib):
     sc.close()
 
 
+def test_update_vertices_without_gpu(prt_lib):
+    """prt_scene_update_vertices on a scene that is not uploaded: triangle precompute, light tree and the host
+    BVH follow the new positions (an uploaded scene rebuilds on the GPU instead; tests/test_gpu_parity.py)."""
+    data = scenes.tiny_scene()
+    sc = api.Scene(data)
+    before = sc.light_order().tolist()
+    moved = data.vertices * np.array([2.0, 1.0, 0.5]) + np.array([0.1, -0.2, 0.3])
+    sc.update_vertices(moved)
+    assert sorted(sc.light_order().tolist()) == sorted(before)
+    assert sc.bvh_info()["n_nodes"] >= 1 and sc.bvh_info()["built_on_device"] == 0
+    with pytest.raises(AssertionError):
+        sc.update_vertices(moved[:-1])
+    sc.close()
+
+
 def test_compute_fails_loudly_without_upload(prt_lib):
     sc = api.Scene(scenes.tiny_scene())
     rays = scenes.random_rays(4, (-1, -1, -1), (1, 1, 1))

@@ -355,6 +355,38 @@ def test_empty_and_lightless_scenes(gpu):
 
 
 @pytest.mark.gpu
+def test_update_vertices_matches_fresh_scene(gpu):
+    """Moving geometry: prt_scene_update_vertices (triangle precompute + light tree on the host, BVH rebuilt on the
+    GPU) must leave the scene exactly as if it had been created from the new positions."""
+    import copy
+    data = scenes.cornell_box(ball_subdiv=3, width=40, height=40)
+    sc = api.Scene(data).upload(gpu)
+    first = sc.render(spp=3, max_depth=5, seed=4)
+    moved = copy.copy(data)
+    v = data.vertices.copy()
+    ball = slice(int(data.mesh_first_tri[-2]), int(data.mesh_first_tri[-1]))  # last mesh = the tessellated ball
+    v[ball] = v[ball] * 0.8 + np.array([0.15, 0.1, -0.2])
+    lights = np.arange(int(data.mesh_first_tri[-3]), int(data.mesh_first_tri[-2]))
+    v[lights] = v[lights] * np.array([1.3, 1.0, 0.7])                          # the light changes area as well
+    moved.vertices = v
+    sc.update_vertices(v)
+    assert sc.bvh_info()["built_on_device"] == 1
+    fresh = api.Scene(moved).upload(gpu)
+    lo, hi = v.reshape(-1, 3).min(0), v.reshape(-1, 3).max(0)
+    rays = scenes.random_rays(100_000, lo, hi, seed=23)
+    a, b = sc.trace_closest(rays), fresh.trace_closest(rays)
+    assert np.array_equal(a["t"], b["t"]) and np.array_equal(a["prim"], b["prim"])
+    org = np.random.default_rng(1).uniform(-0.9, 0.9, size=(5000, 3))
+    la, lb = sc.sample_lights(org, seed=7), fresh.sample_lights(org, seed=7)
+    for f in ("prim", "position", "normal", "pdf", "front"):
+        assert np.array_equal(la[f], lb[f]), f
+    img, ref = sc.render(spp=3, max_depth=5, seed=4), fresh.render(spp=3, max_depth=5, seed=4)
+    assert np.array_equal(img, ref) and not np.array_equal(img, first)
+    cpu, _ = oracle.Oracle(moved).render(spp=3, max_depth=5, seed=4)
+    compare_images(img, cpu)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,scene_fn,nrays", [
     ("tiny", scenes.tiny_scene, 20_000),
     ("cornell", lambda: scenes.cornell_box(ball_subdiv=4, width=48, height=48), 200_000),
