@@ -498,6 +498,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     if (const char* e = std::getenv("PRT_TUNE_KEEP")) P.keep = std::atoi(e);
     if (const char* e = std::getenv("PRT_TUNE_LEAF_BATCH")) P.leaf_batch = std::atoi(e);
     if (const char* e = std::getenv("PRT_TUNE_INNER_MIN")) P.inner_min = std::atoi(e);
+    if (const char* e = std::getenv("PRT_TUNE_SCRAMBLE")) P.scramble = std::atoi(e); // experiment: incoherent pixel order
     for (int c = 0; c < 3; ++c) P.background[c] = p->background[c];
     P.seed = p->seed;
     int tile = p->tile_size > 0 ? p->tile_size : 32;

@@ -678,6 +678,7 @@ PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng) {
 // Owned-pixel index -> pixel.  Tiles are dealt round-robin over ranks; inside a tile pixels are
 // visited in 8x8 blocks so the 64 lanes of a wave start on one compact block.
 PRT_DEV bool owned_to_pixel(const DRenderParams& P, const DCamera& C, uint64_t oi, int& px, int& py) {
+    if (P.scramble) oi = (oi * 2654435761ULL) % P.items_per_chunk; // experiment (odd multiplier; bijective for power-of-two counts)
     const uint32_t tt = (uint32_t)(P.tile * P.tile);
     uint32_t ot = (uint32_t)(oi / tt), w = (uint32_t)(oi % tt);
     uint32_t k = (uint32_t)P.rank + ot * (uint32_t)P.nranks;
