@@ -16,6 +16,9 @@
 #define PRT_LEAF_MAX 4       // triangles per BVH leaf (leaf ref stores count-1 in 3 bits)
 #endif
 #define PRT_BLOCK 256        // threads per workgroup (4 wave64)
+#ifndef PRT_LEAF_PREFETCH
+#define PRT_LEAF_PREFETCH 1   // leaf loop requests the next triangle's plane while testing the current one
+#endif
 #define PRT_MAX_CHUNKS 64    // sample chunks per pixel (work items per pixel)
 
 #ifndef PRT_NODE16
