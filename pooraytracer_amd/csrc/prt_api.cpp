@@ -16,8 +16,9 @@
 #include "prt_host.h"
 
 namespace prt {
-int render_blocks_per_cu(bool count, int feat);
+int render_blocks_per_cu(bool count, int feat, size_t dyn_lds);
 int render_permutation(int feat);
+int render_lds_node_cap(int feat);
 void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hits, DCounters* d_ctr, bool count, int n_cu,
                   hipStream_t st);
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
@@ -63,6 +64,7 @@ struct PrtScene {
     int device = -1;
     int n_cu = 0;
     int blocks_per_cu[2] = {0, 0};
+    int light_lds = 0; // light-tree nodes staged in LDS by K3 (0 = read from global memory)
     int feat = 0; // material features of the scene (1 textures, 2 Phong, 4 CookTorrance) -> K3 permutation
     DScene d{};
     std::vector<void*> allocs;
@@ -360,8 +362,16 @@ int prt_scene_upload(PrtScene* s, int device) {
     }
     if (const char* e = std::getenv("PRT_TUNE_FEAT")) s->feat |= std::atoi(e); // developer: force a larger permutation
     s->feat = prt::render_permutation(s->feat);
-    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat);
-    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat);
+    // The top of a light tree of >= 32 nodes is staged in LDS: its descent is a chain of dependent reads.
+    // (breadth-first numbering: the first 1024 nodes are the top 10 levels = 16 KB).  Measured: veach-mis (5119
+    // nodes, 13 levels) +4.4 % with 1024 nodes staged, +5 % with 2048; scenes with a handful of light triangles
+    // are unaffected either way, so every non-empty tree takes this path.
+    s->light_lds = (int)std::min<size_t>(s->lights.nodes.size(), (size_t)prt::render_lds_node_cap(s->feat));
+    if (const char* e = std::getenv("PRT_TUNE_LIGHT_LDS")) s->light_lds = (int)std::min<size_t>(s->lights.nodes.size(), (size_t)std::max(0, std::atoi(e)));
+    static_assert(sizeof(DLightNode) == 16, "LDS staging copies 16-byte nodes");
+    const size_t dyn_lds = (size_t)s->light_lds * sizeof(DLightNode);
+    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat, dyn_lds);
+    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, dyn_lds);
     return PRT_OK;
 }
 
@@ -510,6 +520,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.rank = p->rank;
     P.nranks = p->nranks;
     P.jitter = p->pixel_jitter ? 1 : 0;
+    P.light_lds = s->light_lds;
     P.owned_tiles = P.n_tiles > P.rank ? (P.n_tiles - P.rank + P.nranks - 1) / P.nranks : 0;
     P.items_per_chunk = (uint64_t)P.owned_tiles * tile * tile;
     const bool count = count_work != 0;

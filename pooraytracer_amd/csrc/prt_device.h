@@ -660,13 +660,19 @@ struct LightPick {
     int32_t tri; // index into light_tris
     bool front;
 };
-PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng) {
+// `lds_nodes` / `n_lds`: the first n_lds nodes (breadth-first numbering = the top levels of the tree) staged in LDS
+// by the kernel, or null / 0.  The descent is a chain of dependent 16-byte reads, one per tree level (13 for
+// veach-mis's 5120 light triangles); from L1/L2 that chain was 11 % of the veach-mis frame.
+template <bool LLDS>
+PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLightNode* lds_nodes = nullptr, int32_t n_lds = 0) {
     (void)rng.next();
     double p = sqrt(rng.next()) * S.light_area;
     float pf = (float)p;
     int32_t node = S.light_root;
     while (node >= 0) {
-        const DLightNode ln = S.light_nodes[node];
+        DLightNode ln;
+        if (LLDS && node < n_lds) ln = lds_nodes[node];
+        else ln = S.light_nodes[node];
         if ((double)pf < ln.left_area) node = ln.left;
         else {
             pf = (float)((double)pf - ln.left_area);

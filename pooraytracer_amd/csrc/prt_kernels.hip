@@ -205,7 +205,7 @@ PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 ro, d3 rd, const HitInfo& h) {
     return c;
 }
 
-template <bool COUNT, int FEAT>
+template <bool COUNT, int FEAT, bool LLDS>
 __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     DScene S, DCamera C, DRenderParams P, double* __restrict__ partial, DCounters* ctr) {
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
@@ -216,6 +216,15 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     if (lane == 0) {
         pool[0] = 0;
         pool[1] = 0;
+    }
+    // light tree in LDS (dynamic allocation sized by the host; see sample_lights)
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    const DLightNode* lds_lights = reinterpret_cast<const DLightNode*>(s_dyn);
+    if (LLDS) { // every thread of the block gets here before any divergence
+        uint4* dst = reinterpret_cast<uint4*>(s_dyn);
+        const uint4* src = reinterpret_cast<const uint4*>(S.light_nodes);
+        for (int i = threadIdx.x; i < P.light_lds; i += PRT_BLOCK) dst[i] = src[i];
+        __syncthreads();
     }
     d3 pst_[2]; // acc (this item's sum of sample radiance / spp), beta (path throughput)
 #define PST_LD(k) (pst_[(k) / 3])
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                             // next-event estimation, Camera.cpp:137-155: pick the light point now (4 draws)
                             const d3 gn = ld3(S.tris[h.tri].n);
                             const d3 fn = dot(rd, gn) < 0. ? gn : -gn;
-                            const LightPick lp = sample_lights(S, pos, rng);
+                            const LightPick lp = sample_lights<LLDS>(S, pos, rng, lds_lights, P.light_lds);
                             double dist;
                             const d3 ldir = normalize_len(lp.pos - pos, dist);
                             if (dot(fn, ldir) > 0.0 && lp.front) {
@@ -541,7 +550,7 @@ __global__ void k_sample_lights(DScene S, const double* __restrict__ origins, si
     if (i >= n) return;
     Rng rng;
     rng.seed(seed, i, 0);
-    const LightPick lp = sample_lights(S, mk3(origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2]), rng);
+    const LightPick lp = sample_lights<false>(S, mk3(origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2]), rng);
     PrtLightSample o;
     o.position[0] = lp.pos.x; o.position[1] = lp.pos.y; o.position[2] = lp.pos.z;
     o.normal[0] = lp.n.x; o.normal[1] = lp.n.y; o.normal[2] = lp.n.z;
@@ -575,19 +584,28 @@ int render_permutation(int feat) {
     return PRT_FEAT_ALL;
 }
 
+// Light-tree nodes (16 bytes each) that fit in LDS next to the traversal stacks without costing a resident block:
+// 160 KB per CU, 32.8 KB of stacks per block, 3 blocks (lean / textured) or 2 (Phong / all).
+int render_lds_node_cap(int feat) { return render_waves(render_permutation(feat)) >= 3 ? 1024 : 2048; }
+
 typedef void (*RenderKernel)(DScene, DCamera, DRenderParams, double*, DCounters*);
-static RenderKernel render_kernel(bool count, int feat) {
+template <int FEAT>
+static RenderKernel render_kernel_feat(bool count, bool llds) {
+    if (count) return llds ? k_render<true, FEAT, true> : k_render<true, FEAT, false>;
+    return llds ? k_render<false, FEAT, true> : k_render<false, FEAT, false>;
+}
+static RenderKernel render_kernel(bool count, int feat, bool llds) {
     switch (render_permutation(feat)) {
-    case 0: return count ? k_render<true, 0> : k_render<false, 0>;
-    case PRT_FEAT_TEX: return count ? k_render<true, PRT_FEAT_TEX> : k_render<false, PRT_FEAT_TEX>;
-    case PRT_FEAT_PHONG: return count ? k_render<true, PRT_FEAT_PHONG> : k_render<false, PRT_FEAT_PHONG>;
-    default: return count ? k_render<true, PRT_FEAT_ALL> : k_render<false, PRT_FEAT_ALL>;
+    case 0: return render_kernel_feat<0>(count, llds);
+    case PRT_FEAT_TEX: return render_kernel_feat<PRT_FEAT_TEX>(count, llds);
+    case PRT_FEAT_PHONG: return render_kernel_feat<PRT_FEAT_PHONG>(count, llds);
+    default: return render_kernel_feat<PRT_FEAT_ALL>(count, llds);
     }
 }
 
-int render_blocks_per_cu(bool count, int feat) {
+int render_blocks_per_cu(bool count, int feat, size_t dyn_lds) {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel(count, feat), PRT_BLOCK, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel(count, feat, dyn_lds != 0), PRT_BLOCK, dyn_lds);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
@@ -603,7 +621,8 @@ void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hit
 
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
                    bool count, int feat, unsigned grid, hipStream_t st) {
-    hipLaunchKernelGGL(render_kernel(count, feat), dim3(grid), dim3(PRT_BLOCK), 0, st, S, C, P, d_partial, d_ctr);
+    const size_t dyn_lds = P.light_lds > 0 ? (size_t)P.light_lds * sizeof(DLightNode) : 0;
+    hipLaunchKernelGGL(render_kernel(count, feat, dyn_lds != 0), dim3(grid), dim3(PRT_BLOCK), dyn_lds, st, S, C, P, d_partial, d_ctr);
 }
 
 void launch_finalize(const DCamera& C, const DRenderParams& P, const double* d_partial, double* d64, float* d32,

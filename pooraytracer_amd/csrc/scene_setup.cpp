@@ -262,6 +262,26 @@ void build_light_tree(const PrtSceneDesc& d, const std::vector<HostTri>& tris, c
     const int32_t top = rb.build(lights, 0, lights.size()); // lights = HittableList(BVHNode(lights)) main.cpp:45
     out.area = rb.nodes[top].area;
     out.root = flatten_light(rb, Obj{-1, top}, out, tris);
+    // Breadth-first numbering: the first K nodes are the top levels, which K3 stages in LDS (the descent is a chain
+    // of dependent reads, one per level).  The leaf (CDF) order and every area stay as built.
+    if (out.root >= 0) {
+        std::vector<int32_t> order{out.root}, newidx(out.nodes.size(), -1);
+        for (size_t q = 0; q < order.size(); ++q) {
+            const DLightNode& n = out.nodes[order[q]];
+            if (n.left >= 0) order.push_back(n.left);
+            if (n.right >= 0) order.push_back(n.right);
+        }
+        for (size_t i = 0; i < order.size(); ++i) newidx[order[i]] = (int32_t)i;
+        std::vector<DLightNode> renum(order.size());
+        for (size_t i = 0; i < order.size(); ++i) {
+            DLightNode n = out.nodes[order[i]];
+            if (n.left >= 0) n.left = newidx[n.left];
+            if (n.right >= 0) n.right = newidx[n.right];
+            renum[i] = n;
+        }
+        out.nodes.swap(renum);
+        out.root = 0;
+    }
     for (DLightTri& lt : out.tris) { // Triangle::Sample pdf = 1/area; TraverseSample pdf *= area; BVHNode::Sample pdf /= total
         double pdf = 1.0 / lt.area;
         pdf *= lt.area;
