@@ -64,7 +64,7 @@ struct PrtScene {
     int device = -1;
     int n_cu = 0;
     int blocks_per_cu[2] = {0, 0};
-    int light_lds = 0; // light-tree nodes staged in LDS by K3 (0 = read from global memory)
+    int light_lds = 0, mat_lds = 0; // light-tree nodes / materials staged in LDS by K3 (both 0 = the kernels without LDS tables)
     int feat = 0; // material features of the scene (1 textures, 2 Phong, 4 CookTorrance) -> K3 permutation
     DScene d{};
     std::vector<void*> allocs;
@@ -369,7 +369,10 @@ int prt_scene_upload(PrtScene* s, int device) {
     s->light_lds = (int)std::min<size_t>(s->lights.nodes.size(), (size_t)prt::render_lds_node_cap(s->feat));
     if (const char* e = std::getenv("PRT_TUNE_LIGHT_LDS")) s->light_lds = (int)std::min<size_t>(s->lights.nodes.size(), (size_t)std::max(0, std::atoi(e)));
     static_assert(sizeof(DLightNode) == 16, "LDS staging copies 16-byte nodes");
-    const size_t dyn_lds = (size_t)s->light_lds * sizeof(DLightNode);
+    s->mat_lds = (int)s->mats.size();
+    if (s->mats.size() * sizeof(DMaterial) > 8192 || s->mats.empty()) s->light_lds = s->mat_lds = 0; // table too large for LDS: plain kernels
+    if (const char* e = std::getenv("PRT_TUNE_NO_LDS")) if (std::atoi(e)) s->light_lds = s->mat_lds = 0;
+    const size_t dyn_lds = (size_t)s->light_lds * sizeof(DLightNode) + (size_t)s->mat_lds * sizeof(DMaterial);
     s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat, dyn_lds);
     s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, dyn_lds);
     return PRT_OK;
@@ -521,6 +524,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.nranks = p->nranks;
     P.jitter = p->pixel_jitter ? 1 : 0;
     P.light_lds = s->light_lds;
+    P.mat_lds = s->mat_lds;
     P.owned_tiles = P.n_tiles > P.rank ? (P.n_tiles - P.rank + P.nranks - 1) / P.nranks : 0;
     P.items_per_chunk = (uint64_t)P.owned_tiles * tile * tile;
     const bool count = count_work != 0;

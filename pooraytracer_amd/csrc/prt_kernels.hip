@@ -220,12 +220,20 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     // light tree in LDS (dynamic allocation sized by the host; see sample_lights)
     extern __shared__ __align__(16) unsigned char s_dyn[];
     const DLightNode* lds_lights = reinterpret_cast<const DLightNode*>(s_dyn);
+    // ... followed by the whole material table (the host only selects LLDS when it fits): its fields are read
+    // several times per path vertex, and every one of those reads is otherwise a texture-addresser instruction
+    const DMaterial* lds_mats = reinterpret_cast<const DMaterial*>(s_dyn + (size_t)P.light_lds * sizeof(DLightNode));
     if (LLDS) { // every thread of the block gets here before any divergence
         uint4* dst = reinterpret_cast<uint4*>(s_dyn);
         const uint4* src = reinterpret_cast<const uint4*>(S.light_nodes);
         for (int i = threadIdx.x; i < P.light_lds; i += PRT_BLOCK) dst[i] = src[i];
+        dst += P.light_lds;
+        src = reinterpret_cast<const uint4*>(S.materials);
+        const int nm = P.mat_lds * (int)(sizeof(DMaterial) / 16);
+        for (int i = threadIdx.x; i < nm; i += PRT_BLOCK) dst[i] = src[i];
         __syncthreads();
     }
+#define MATERIAL(i) (LLDS ? lds_mats[(i)] : S.materials[(i)])
     d3 pst_[2]; // acc (this item's sum of sample radiance / spp), beta (path throughput)
 #define PST_LD(k) (pst_[(k) / 3])
 #define PST_ST(k, v) (pst_[(k) / 3] = (v))
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     if (first || !P.sample_lights) ADD_RADIANCE(ld3(P.background));
                     end_sample = true;
                 } else {
-                    const DMaterial& m = S.materials[S.shade[h.tri].material];
+                    const DMaterial& m = MATERIAL(S.shade[h.tri].material);
                     if (m.has_emission) {
                         // Camera.cpp:129-132; via a bounce only after SkipLightSampling materials (:191-195)
                         if (first || !P.sample_lights || prev_skip) ADD_RADIANCE(ld3(m.emission));
@@ -326,13 +334,13 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     sh.beta = sh_beta;
                     sh.tri = sh_tri;
                     const ShadeCtx c = make_ctx<FEAT>(S, to, rd, sh);
-                    const DMaterial& m = S.materials[c.material];
+                    const DMaterial& m = MATERIAL(c.material);
                     const DLightTri* lt = S.light_tris + ltri;
                     const d3 ln0 = ld3(lt->n);
                     // SetFaceNormal(Ray(origin, p - origin), normal) (Triangle.cpp:89-90); p - origin = td * dist
                     const d3 ln = dot(td, ln0) < 0. ? ln0 : -ln0;
                     const double pdf = lt->pdf;                              // Triangle.cpp:92, BVH.cpp:91,66
-                    const d3 emission = ld3(S.materials[lt->material].emission);
+                    const d3 emission = ld3(MATERIAL(lt->material).emission);
                     const d3 wo = world_to_local(-rd, c.f);
                     const d3 lwi = world_to_local(td, c.f);
                     const d3 lln = world_to_local(ln, c.f);
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     sh.beta = sh_beta;
                     sh.tri = sh_tri;
                     const ShadeCtx c = make_ctx<FEAT>(S, pos, rd, sh);
-                    const DMaterial& m = S.materials[c.material];
+                    const DMaterial& m = MATERIAL(c.material);
                     d3 att, wi;
                     if (mat_scatter<FEAT>(S, m, rd, c.f, c.uv, rng, att, wi)) {
                         depth--; // RayColor(scattered, depth-1): returns 0 when depth-1 < 0
@@ -586,7 +594,7 @@ int render_permutation(int feat) {
 
 // Light-tree nodes (16 bytes each) that fit in LDS next to the traversal stacks without costing a resident block:
 // 160 KB per CU, 32.8 KB of stacks per block, 3 blocks (lean / textured) or 2 (Phong / all).
-int render_lds_node_cap(int feat) { return render_waves(render_permutation(feat)) >= 3 ? 1024 : 2048; }
+int render_lds_node_cap(int feat) { return render_waves(render_permutation(feat)) >= 3 ? 832 : 2048; } // + 8 KB of materials
 
 typedef void (*RenderKernel)(DScene, DCamera, DRenderParams, double*, DCounters*);
 template <int FEAT>
@@ -621,7 +629,8 @@ void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hit
 
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
                    bool count, int feat, unsigned grid, hipStream_t st) {
-    const size_t dyn_lds = P.light_lds > 0 ? (size_t)P.light_lds * sizeof(DLightNode) : 0;
+    static_assert(sizeof(DMaterial) % 16 == 0, "materials are staged in 16-byte pieces");
+    const size_t dyn_lds = (size_t)P.light_lds * sizeof(DLightNode) + (size_t)P.mat_lds * sizeof(DMaterial);
     hipLaunchKernelGGL(render_kernel(count, feat, dyn_lds != 0), dim3(grid), dim3(PRT_BLOCK), dyn_lds, st, S, C, P, d_partial, d_ctr);
 }
 
