@@ -18,7 +18,7 @@
 namespace prt {
 int render_blocks_per_cu(bool count, int feat, size_t dyn_lds);
 int render_permutation(int feat);
-int render_lds_node_cap(int feat);
+int render_lds_budget(int feat);
 void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hits, DCounters* d_ctr, bool count, int n_cu,
                   hipStream_t st);
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
@@ -64,6 +64,7 @@ struct PrtScene {
     int device = -1;
     int n_cu = 0;
     int blocks_per_cu[2] = {0, 0};
+    int ltri_lds = 0;
     int light_lds = 0, mat_lds = 0; // light-tree nodes / materials staged in LDS by K3 (both 0 = the kernels without LDS tables)
     int feat = 0; // material features of the scene (1 textures, 2 Phong, 4 CookTorrance) -> K3 permutation
     DScene d{};
@@ -362,17 +363,30 @@ int prt_scene_upload(PrtScene* s, int device) {
     }
     if (const char* e = std::getenv("PRT_TUNE_FEAT")) s->feat |= std::atoi(e); // developer: force a larger permutation
     s->feat = prt::render_permutation(s->feat);
-    // The top of a light tree of >= 32 nodes is staged in LDS: its descent is a chain of dependent reads.
-    // (breadth-first numbering: the first 1024 nodes are the top 10 levels = 16 KB).  Measured: veach-mis (5119
-    // nodes, 13 levels) +4.4 % with 1024 nodes staged, +5 % with 2048; scenes with a handful of light triangles
-    // are unaffected either way, so every non-empty tree takes this path.
-    s->light_lds = (int)std::min<size_t>(s->lights.nodes.size(), (size_t)prt::render_lds_node_cap(s->feat));
-    if (const char* e = std::getenv("PRT_TUNE_LIGHT_LDS")) s->light_lds = (int)std::min<size_t>(s->lights.nodes.size(), (size_t)std::max(0, std::atoi(e)));
-    static_assert(sizeof(DLightNode) == 16, "LDS staging copies 16-byte nodes");
-    s->mat_lds = (int)s->mats.size();
-    if (s->mats.size() * sizeof(DMaterial) > 8192 || s->mats.empty()) s->light_lds = s->mat_lds = 0; // table too large for LDS: plain kernels
-    if (const char* e = std::getenv("PRT_TUNE_NO_LDS")) if (std::atoi(e)) s->light_lds = s->mat_lds = 0;
-    const size_t dyn_lds = (size_t)s->light_lds * sizeof(DLightNode) + (size_t)s->mat_lds * sizeof(DMaterial);
+    // Small read-only tables of the shading code live in LDS (LLDS kernels): every read of them is otherwise a
+    // texture-addresser instruction, and the light tree's descent is a chain of dependent reads.  In order of
+    // value per byte: the material table (must fit, <= 8 KB), all light triangles if there are at most 32, then
+    // as many top levels of the light tree (breadth-first numbering) as the remaining budget holds.
+    // Measured: materials cornell +2.5 %, bathroom2 +3 %, veach-mis +2 %; light tree veach-mis +5 %.
+    {
+        int budget = prt::render_lds_budget(s->feat);
+        s->mat_lds = s->ltri_lds = s->light_lds = 0;
+        const bool off = std::getenv("PRT_TUNE_NO_LDS") && std::atoi(std::getenv("PRT_TUNE_NO_LDS"));
+        if (!off && !s->mats.empty() && s->mats.size() * sizeof(DMaterial) <= 8192) {
+            s->mat_lds = (int)s->mats.size();
+            budget -= s->mat_lds * (int)sizeof(DMaterial);
+            if (!s->lights.tris.empty() && s->lights.tris.size() <= 32) {
+                s->ltri_lds = (int)s->lights.tris.size();
+                budget -= s->ltri_lds * (int)sizeof(DLightTri);
+            }
+            s->light_lds = (int)std::min<size_t>(s->lights.nodes.size(), (size_t)(budget / (int)sizeof(DLightNode)));
+            if (const char* e = std::getenv("PRT_TUNE_LIGHT_LDS")) s->light_lds = std::min(s->light_lds, std::max(0, std::atoi(e)));
+            if (const char* e = std::getenv("PRT_TUNE_LTRI_LDS")) if (!std::atoi(e)) s->ltri_lds = 0;
+        }
+    }
+    static_assert(sizeof(DLightNode) == 16 && sizeof(DLightTri) % 16 == 0, "LDS staging copies 16-byte pieces");
+    const size_t dyn_lds = (size_t)s->light_lds * sizeof(DLightNode) + (size_t)s->mat_lds * sizeof(DMaterial) +
+                           (size_t)s->ltri_lds * sizeof(DLightTri);
     s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat, dyn_lds);
     s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, dyn_lds);
     return PRT_OK;
@@ -525,6 +539,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.jitter = p->pixel_jitter ? 1 : 0;
     P.light_lds = s->light_lds;
     P.mat_lds = s->mat_lds;
+    P.ltri_lds = s->ltri_lds;
     P.owned_tiles = P.n_tiles > P.rank ? (P.n_tiles - P.rank + P.nranks - 1) / P.nranks : 0;
     P.items_per_chunk = (uint64_t)P.owned_tiles * tile * tile;
     const bool count = count_work != 0;

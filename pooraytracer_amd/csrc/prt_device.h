@@ -664,7 +664,8 @@ struct LightPick {
 // by the kernel, or null / 0.  The descent is a chain of dependent 16-byte reads, one per tree level (13 for
 // veach-mis's 5120 light triangles); from L1/L2 that chain was 11 % of the veach-mis frame.
 template <bool LLDS>
-PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLightNode* lds_nodes = nullptr, int32_t n_lds = 0) {
+PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLightNode* lds_nodes = nullptr, int32_t n_lds = 0,
+                                const DLightTri* lds_tris = nullptr, int32_t n_tris_lds = 0) {
     (void)rng.next();
     double p = sqrt(rng.next()) * S.light_area;
     float pf = (float)p;
@@ -681,15 +682,22 @@ PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLig
     }
     LightPick lp;
     lp.tri = ~node;
-    const DLightTri* lt = S.light_tris + lp.tri;
     double x = sqrt(rng.next());
     double y = rng.next();
-    d3 v0 = ld3(lt->v0), v1 = ld3(lt->v1), v2 = ld3(lt->v2), n = ld3(lt->n);
+    d3 v0, v1, v2, n;
+    if (LLDS && n_tris_lds > 0) { // uniform: a scene's light triangles are staged all or not at all
+        const DLightTri* lt = lds_tris + lp.tri;
+        v0 = ld3(lt->v0); v1 = ld3(lt->v1); v2 = ld3(lt->v2); n = ld3(lt->n);
+        lp.pdf = lt->pdf;
+    } else {
+        const DLightTri* lt = S.light_tris + lp.tri;
+        v0 = ld3(lt->v0); v1 = ld3(lt->v1); v2 = ld3(lt->v2); n = ld3(lt->n);
+        lp.pdf = lt->pdf; // (1/area)*area/total_area, evaluated in that order on the host
+    }
     lp.pos = v0 * (1.0 - x) + v1 * (x * (1.0 - y)) + v2 * (x * y);
     d3 dir = lp.pos - origin;
     lp.front = dot(dir, n) < 0.;
     lp.n = lp.front ? n : -n;
-    lp.pdf = lt->pdf; // (1/area)*area/total_area, evaluated in that order on the host
     return lp;
 }
 

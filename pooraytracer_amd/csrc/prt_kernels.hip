@@ -223,6 +223,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     // ... followed by the whole material table (the host only selects LLDS when it fits): its fields are read
     // several times per path vertex, and every one of those reads is otherwise a texture-addresser instruction
     const DMaterial* lds_mats = reinterpret_cast<const DMaterial*>(s_dyn + (size_t)P.light_lds * sizeof(DLightNode));
+    const DLightTri* lds_ltris = reinterpret_cast<const DLightTri*>(s_dyn + (size_t)P.light_lds * sizeof(DLightNode) + (size_t)P.mat_lds * sizeof(DMaterial));
     if (LLDS) { // every thread of the block gets here before any divergence
         uint4* dst = reinterpret_cast<uint4*>(s_dyn);
         const uint4* src = reinterpret_cast<const uint4*>(S.light_nodes);
@@ -231,6 +232,10 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
         src = reinterpret_cast<const uint4*>(S.materials);
         const int nm = P.mat_lds * (int)(sizeof(DMaterial) / 16);
         for (int i = threadIdx.x; i < nm; i += PRT_BLOCK) dst[i] = src[i];
+        dst += nm;
+        src = reinterpret_cast<const uint4*>(S.light_tris);
+        const int nl = P.ltri_lds * (int)(sizeof(DLightTri) / 16);
+        for (int i = threadIdx.x; i < nl; i += PRT_BLOCK) dst[i] = src[i];
         __syncthreads();
     }
 #define MATERIAL(i) (LLDS ? lds_mats[(i)] : S.materials[(i)])
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                             // next-event estimation, Camera.cpp:137-155: pick the light point now (4 draws)
                             const d3 gn = ld3(S.tris[h.tri].n);
                             const d3 fn = dot(rd, gn) < 0. ? gn : -gn;
-                            const LightPick lp = sample_lights<LLDS>(S, pos, rng, lds_lights, P.light_lds);
+                            const LightPick lp = sample_lights<LLDS>(S, pos, rng, lds_lights, P.light_lds, lds_ltris, P.ltri_lds);
                             double dist;
                             const d3 ldir = normalize_len(lp.pos - pos, dist);
                             if (dot(fn, ldir) > 0.0 && lp.front) {
@@ -335,12 +340,19 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     sh.tri = sh_tri;
                     const ShadeCtx c = make_ctx<FEAT>(S, to, rd, sh);
                     const DMaterial& m = MATERIAL(c.material);
-                    const DLightTri* lt = S.light_tris + ltri;
-                    const d3 ln0 = ld3(lt->n);
+                    d3 ln0;
+                    double pdf;
+                    int32_t lmat;
+                    if (LLDS && P.ltri_lds > 0) {
+                        const DLightTri* lt = lds_ltris + ltri;
+                        ln0 = ld3(lt->n); pdf = lt->pdf; lmat = lt->material;
+                    } else {
+                        const DLightTri* lt = S.light_tris + ltri;
+                        ln0 = ld3(lt->n); pdf = lt->pdf; lmat = lt->material;   // Triangle.cpp:92, BVH.cpp:91,66
+                    }
                     // SetFaceNormal(Ray(origin, p - origin), normal) (Triangle.cpp:89-90); p - origin = td * dist
                     const d3 ln = dot(td, ln0) < 0. ? ln0 : -ln0;
-                    const double pdf = lt->pdf;                              // Triangle.cpp:92, BVH.cpp:91,66
-                    const d3 emission = ld3(MATERIAL(lt->material).emission);
+                    const d3 emission = ld3(MATERIAL(lmat).emission);
                     const d3 wo = world_to_local(-rd, c.f);
                     const d3 lwi = world_to_local(td, c.f);
                     const d3 lln = world_to_local(ln, c.f);
@@ -594,7 +606,8 @@ int render_permutation(int feat) {
 
 // Light-tree nodes (16 bytes each) that fit in LDS next to the traversal stacks without costing a resident block:
 // 160 KB per CU, 32.8 KB of stacks per block, 3 blocks (lean / textured) or 2 (Phong / all).
-int render_lds_node_cap(int feat) { return render_waves(render_permutation(feat)) >= 3 ? 832 : 2048; } // + 8 KB of materials
+// Bytes of dynamic LDS a block may use without costing a resident block: 160 KB per CU, 32832 B static per block.
+int render_lds_budget(int feat) { return render_waves(render_permutation(feat)) >= 3 ? 21504 : 48640; }
 
 typedef void (*RenderKernel)(DScene, DCamera, DRenderParams, double*, DCounters*);
 template <int FEAT>
@@ -630,7 +643,8 @@ void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hit
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
                    bool count, int feat, unsigned grid, hipStream_t st) {
     static_assert(sizeof(DMaterial) % 16 == 0, "materials are staged in 16-byte pieces");
-    const size_t dyn_lds = (size_t)P.light_lds * sizeof(DLightNode) + (size_t)P.mat_lds * sizeof(DMaterial);
+    const size_t dyn_lds = (size_t)P.light_lds * sizeof(DLightNode) + (size_t)P.mat_lds * sizeof(DMaterial) +
+                           (size_t)P.ltri_lds * sizeof(DLightTri);
     hipLaunchKernelGGL(render_kernel(count, feat, dyn_lds != 0), dim3(grid), dim3(PRT_BLOCK), dyn_lds, st, S, C, P, d_partial, d_ctr);
 }
 

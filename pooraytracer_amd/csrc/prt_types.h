@@ -129,7 +129,8 @@ struct DRenderParams {
     int32_t tile, tiles_x, tiles_y, n_tiles;
     int32_t rank, nranks, owned_tiles, jitter; // jitter: per-sample SampleSquare pixel offset (Camera.cpp:110-111)
     int32_t keep, leaf_batch, inner_min, scramble;
-    int32_t light_lds, mat_lds; // LLDS kernels: light-tree nodes / materials staged in (dynamic) LDS by K3 // wave scheduling thresholds of K3 (see prt_kernels.hip)
+    int32_t light_lds, mat_lds; // LLDS kernels: light-tree nodes / materials staged in (dynamic) LDS by K3
+    int32_t ltri_lds, pad4;     // ... and ALL light triangles (n_lights) when there are at most 32 of them, else 0 // wave scheduling thresholds of K3 (see prt_kernels.hip)
     uint64_t items_per_chunk; // owned_tiles * tile * tile
     uint64_t n_items;         // items_per_chunk * chunks
     int32_t chunk_begin[PRT_MAX_CHUNKS + 1]; // chunk c covers samples [chunk_begin[c], chunk_begin[c+1])
