@@ -425,3 +425,28 @@ def test_device_bvh_build_gives_identical_results(gpu, name, scene_fn, nrays):
     # determinism of the builder's results across two builds
     dev2 = api.Scene(data, device_bvh=True).upload(gpu)
     assert np.array_equal(dev2.trace_closest(rays)["t"], b["t"])
+
+
+@pytest.mark.gpu
+def test_lds_tables_and_plain_kernels_agree(gpu, monkeypatch):
+    """K3 has two kernel families: with the material table / light triangles / top of the light tree staged in LDS
+    (default when the materials fit in 8 KB) and without.  Same arithmetic, so the images must be bit-identical —
+    on a few-light scene (light triangles staged), a many-light scene (only the top of the tree staged, the rest
+    read from global memory) and a scene with more materials than fit (falls back to the plain kernels).  The two
+    families are separate compilations of the same source (fused multiply-adds may be formed differently), so
+    the comparison uses the image tolerance rather than bit equality."""
+    import copy
+    few = scenes.mixed_materials(40, 32)
+    many = scenes.veach_mis(64, 36, light_subdiv=3, plate_cells=2)          # 5120 light triangles, 13 tree levels
+    big = copy.copy(few)
+    big.materials = list(few.materials) + [few.materials[0]] * 60             # 60+ materials: > 8 KB
+    for data, kw in ((few, dict(spp=6, max_depth=6)), (many, dict(spp=4, max_depth=8)), (big, dict(spp=3, max_depth=4))):
+        monkeypatch.delenv("PRT_TUNE_NO_LDS", raising=False)
+        a = api.Scene(data).upload(gpu).render(seed=11, **kw)
+        monkeypatch.setenv("PRT_TUNE_NO_LDS", "1")
+        b = api.Scene(data).upload(gpu).render(seed=11, **kw)
+        compare_images(a, b)
+        assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max())
+    monkeypatch.delenv("PRT_TUNE_NO_LDS", raising=False)
+    cpu, _ = oracle.Oracle(many).render(spp=4, max_depth=8, seed=11, nthreads=8)
+    compare_images(api.Scene(many).upload(gpu).render(spp=4, max_depth=8, seed=11), cpu)
