@@ -191,3 +191,50 @@ def test_golden_fixture(name):
     assert np.array_equal(h["prim"], g["hit_prim"])
     assert np.allclose(h["t"], g["hit_t"], rtol=1e-13)
     assert np.array_equal(o.light_order(), g["light_order"])
+
+
+def _direct_light_scene():
+    """A Lambertian floor (kd 0.5) at y=0 under ONE emissive triangle at y=1 facing down, seen from above."""
+    b = scenes._Builder("direct")
+    floor = b.material(scenes.Material("DiffuseWhite", _abi.MAT_LAMBERTIAN, kd=(0.5, 0.5, 0.5)))
+    light = b.material(scenes.Material("Light", _abi.MAT_DIFFUSE_LIGHT, emission=(10.0, 8.0, 6.0)))
+    fv = np.array([[[-4, 0, -4], [-4, 0, 4], [4, 0, 4]], [[-4, 0, -4], [4, 0, 4], [4, 0, -4]]], dtype=np.float64)
+    b.mesh("floor", floor, fv, np.zeros((2, 3, 2)))
+    lv = np.array([[[-0.5, 1, -0.5], [0.5, 1, -0.5], [0.0, 1, 0.5]]], dtype=np.float64)  # normal (0,-1,0)
+    b.mesh("light", light, lv, np.zeros((1, 3, 2)))
+    # the eye sits beside the light, so no camera ray of the sampled pixels meets the light itself
+    return b.build(scenes.Camera(8, 8, 20.0, (2.5, 3.0, 0.0), (0.6, 0.0, 0.1), up=(0.0, 0.0, -1.0))), lv[0]
+
+
+def test_direct_lighting_matches_the_area_integral():
+    """Physics check that does not lean on the reference: with maxDepth 0 a pixel's radiance is the next-event
+    estimate alone (Camera.cpp:137-172), whose expectation for one Lambertian point under one emissive triangle is
+    L = integral over the light of Le * (kd/pi) * cos(theta_x) * cos(theta_l) / r^2 dA.  The oracle's mean over
+    many samples must agree with a dense quadrature of that integral (a single light triangle, so the sqrt-skewed
+    CDF of BVH.cpp:62-67 cannot bias the pick)."""
+    sc, tri = _direct_light_scene()
+    o = oracle.Oracle(sc)
+    rays = oracle.camera_rays(sc.camera)
+    spp = 20000
+    for (i, j) in ((3, 3), (5, 2)):
+        org, d = rays[j, i, :3], rays[j, i, 3:]
+        t = -org[1] / d[1]                       # floor y = 0
+        x = org + t * d
+        h = o.trace_closest(mkrays([org], [d]))
+        assert h["prim"][0] in (0, 1) and abs(h["t"][0] - t) < 1e-12
+        # quadrature: n x n sub-triangles of the light, midpoint rule
+        n = 400
+        u, v = np.meshgrid((np.arange(n) + 0.5) / n, (np.arange(n) + 0.5) / n, indexing="ij")
+        keep = u + v < 1.0
+        u, v = u[keep], v[keep]
+        p = tri[0] + u[:, None] * (tri[1] - tri[0]) + v[:, None] * (tri[2] - tri[0])
+        w = (x - p)
+        r2 = (w * w).sum(1)
+        cos_l = np.abs(w[:, 1]) / np.sqrt(r2)    # light normal (0,-1,0), floor normal (0,1,0)
+        cos_x = cos_l
+        area = 0.5 * np.linalg.norm(np.cross(tri[1] - tri[0], tri[2] - tri[0]))
+        geom = (cos_x * cos_l / r2).mean() * area * (keep.sum() / (0.5 * n * n))  # cells cut by the hypotenuse
+        expect = np.array([10.0, 8.0, 6.0]) * (0.5 / np.pi) * geom
+        s = o.render_samples([(i, j)], spp=spp, max_depth=0, seed=5)[0]
+        mean, sem = s.mean(0), s.std(0) / np.sqrt(spp)
+        assert np.all(np.abs(mean - expect) < 4 * sem + 2e-3 * expect), (mean, expect, sem)
