@@ -17,7 +17,7 @@ def run(label, reps=3, **kw):
 
 nr = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 for env in ({}, {"PRT_TUNE_VAR": "1"}, {"PRT_TUNE_VAR": "2"}, {"PRT_TUNE_VAR": "4"}, {"PRT_TUNE_VAR": "6"},
-            {"PRT_TUNE_BODY": "64"}, {"PRT_TUNE_BODY": "256"}, {"PRT_TUNE_VAR": "4", "PRT_TUNE_BODY": "64"}):
+            {"PRT_TUNE_BODY": "32"}, {"PRT_TUNE_BODY": "128"}, {"PRT_TUNE_VAR": "4", "PRT_TUNE_BODY": "64"}):
     for k in ("PRT_TUNE_VAR", "PRT_TUNE_BODY", "PRT_TUNE_KEEP"):
         os.environ.pop(k, None)
     os.environ.update(env)
