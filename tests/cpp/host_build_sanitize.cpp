@@ -1,0 +1,124 @@
+// Test helper (built with -fsanitize=address,undefined): the host-side scene preparation of libprt_hip —
+// Triangle precompute, binned-SAH BVH with 16-bit quantised boxes, light tree — on random and degenerate
+// input, with the tree invariants checked: every triangle in exactly one leaf, every leaf's triangles inside
+// its (dequantised) box, child boxes inside the parent's, depth within the traversal stack.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../pooraytracer_amd/csrc/prt_host.h"
+
+using namespace prt;
+
+static int fail(const char* what) {
+    std::fprintf(stderr, "FAILED: %s\n", what);
+    return 1;
+}
+
+struct Box {
+    double lo[3], hi[3];
+};
+
+static int check_tree(const BuiltBVH& b, const std::vector<HostTri>& tris) {
+    const size_t n = tris.size();
+    std::vector<int> seen(n, 0);
+    auto deq = [&](const uint16_t q[2], int a, double& lo, double& hi) {
+        lo = (double)b.grid_origin[a] + (double)q[0] * (double)b.grid_step[a];
+        hi = (double)b.grid_origin[a] + (double)q[1] * (double)b.grid_step[a];
+    };
+    struct Item { int32_t ref; Box box; uint32_t depth; };
+    std::vector<Item> stack;
+    Box all;
+    for (int a = 0; a < 3; ++a) { all.lo[a] = -1e300; all.hi[a] = 1e300; }
+    stack.push_back({0, all, 0});
+    uint32_t max_depth = 0;
+    while (!stack.empty()) {
+        Item it = stack.back();
+        stack.pop_back();
+        if (it.depth > max_depth) max_depth = it.depth;
+        if (it.ref < 0) {
+            const uint32_t enc = ~(uint32_t)it.ref, first = enc >> 3, cnt = (enc & 7u) + 1u;
+            if (cnt > PRT_LEAF_MAX || first + cnt > n) return fail("leaf range");
+            for (uint32_t i = first; i < first + cnt; ++i) {
+                const HostTri& T = tris[b.order[i]];
+                seen[b.order[i]]++;
+                for (int a = 0; a < 3; ++a)
+                    if (T.lo[a] < it.box.lo[a] || T.hi[a] > it.box.hi[a]) return fail("triangle outside its leaf box");
+            }
+            continue;
+        }
+        if ((size_t)it.ref >= b.nodes.size()) return fail("node index");
+        const DNode& nd = b.nodes[it.ref];
+        Box c0, c1;
+        deq(nd.c0x, 0, c0.lo[0], c0.hi[0]); deq(nd.c0y, 1, c0.lo[1], c0.hi[1]); deq(nd.c0z, 2, c0.lo[2], c0.hi[2]);
+        deq(nd.c1x, 0, c1.lo[0], c1.hi[0]); deq(nd.c1y, 1, c1.lo[1], c1.hi[1]); deq(nd.c1z, 2, c1.lo[2], c1.hi[2]);
+        stack.push_back({nd.ref0, c0, it.depth + 1});
+        if (!(n == 1 && nd.ref1 == nd.ref0)) stack.push_back({nd.ref1, c1, it.depth + 1});
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (seen[i] != 1) return fail("triangle not in exactly one leaf");
+    if (max_depth > PRT_STACK_DEPTH - 1) return fail("tree deeper than the traversal stack");
+    return 0;
+}
+
+int main() {
+    std::mt19937_64 rng(99);
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    for (int round = 0; round < 5; ++round) {
+        const size_t n = round == 0 ? 1 : round == 1 ? 2 : round == 2 ? 37 : round == 3 ? 5000 : 60000;
+        std::vector<double> v(n * 9), uv(n * 6), nr(n * 9, 0.0);
+        for (size_t t = 0; t < n; ++t) {
+            const double cx = U(rng) * 10 - 5, cy = U(rng) * 2, cz = U(rng) * 10 - 5;
+            const double s = (t % 97 == 0) ? 3.0 : 0.02 + 0.1 * U(rng); // a few large triangles among small ones
+            for (int k = 0; k < 3; ++k) {
+                v[t * 9 + k * 3 + 0] = cx + s * (U(rng) - 0.5);
+                v[t * 9 + k * 3 + 1] = cy + s * (U(rng) - 0.5);
+                v[t * 9 + k * 3 + 2] = cz + s * (U(rng) - 0.5);
+                uv[t * 6 + k * 2] = U(rng);
+                uv[t * 6 + k * 2 + 1] = U(rng);
+            }
+            if (t % 211 == 5) // degenerate: all three vertices equal (NaN normal -> fallbacks)
+                for (int k = 1; k < 3; ++k)
+                    for (int a = 0; a < 3; ++a) v[t * 9 + k * 3 + a] = v[t * 9 + a];
+            if (t % 223 == 7) // degenerate texture coordinates (tangent fallback)
+                for (int k = 0; k < 3; ++k) uv[t * 6 + k * 2] = uv[t * 6 + k * 2 + 1] = 0.25;
+        }
+        PrtMaterial mats[2] = {};
+        mats[0].type = PRT_MAT_LAMBERTIAN; mats[0].texture = -1; mats[0].kd[0] = mats[0].kd[1] = mats[0].kd[2] = 0.5;
+        mats[1].type = PRT_MAT_DIFFUSE_LIGHT; mats[1].texture = -1; mats[1].emission[0] = 5;
+        const size_t n_light = n >= 37 ? n / 10 : 0;
+        const uint64_t first[3] = {0, n - n_light, n};
+        const int32_t mm[2] = {0, 1};
+        PrtSceneDesc d = {};
+        d.n_tris = n; d.vertices = v.data(); d.normals = nr.data(); d.texcoords = uv.data();
+        d.n_meshes = n_light ? 2 : 1; d.n_materials = 2; d.mesh_first_tri = first; d.mesh_material = mm; d.materials = mats;
+        const uint64_t first1[2] = {0, n};
+        if (!n_light) d.mesh_first_tri = first1;
+        std::vector<HostTri> tris;
+        setup_triangles(d, tris);
+        std::vector<DMaterial> dm;
+        setup_materials(d, dm);
+        LightTree lt;
+        build_light_tree(d, tris, dm, lt);
+        if (lt.tris.size() != n_light) return fail("light triangle count");
+        if (n_light && (lt.root != 0 && lt.nodes.size() > 0)) return fail("light tree root is not node 0 after renumbering");
+        for (const DLightNode& ln : lt.nodes)
+            if ((ln.left >= 0 && (size_t)ln.left >= lt.nodes.size()) || (ln.right >= 0 && (size_t)ln.right >= lt.nodes.size()) ||
+                (ln.left < 0 && (size_t)(~ln.left) >= lt.tris.size()) || (ln.right < 0 && (size_t)(~ln.right) >= lt.tris.size()))
+                return fail("light tree reference out of range");
+        BuiltBVH b;
+        std::string err;
+        if (!build_bvh(tris, b, &err)) return fail(err.c_str());
+        if (b.order.size() != n) return fail("order size");
+        if (check_tree(b, tris)) return 1;
+        std::vector<double> moved(v);
+        for (double& x : moved) x = x * 1.5 + 0.25;
+        update_triangles(moved.data(), nullptr, tris);
+        if (!build_bvh(tris, b, &err) || check_tree(b, tris)) return fail("rebuild after update_triangles");
+        std::printf("n=%zu nodes=%zu depth=%u lights=%zu ok\n", n, b.nodes.size(), b.depth, lt.tris.size());
+    }
+    return 0;
+}
