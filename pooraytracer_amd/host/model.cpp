@@ -115,9 +115,9 @@ struct Shape {
     std::vector<int> material_ids; // per face
 };
 
-int fix_index(long i, size_t n) { // OBJ: 1-based, negative = relative to the end
-    if (i > 0) return (int)i - 1;
-    if (i < 0) return (int)n + (int)i;
+int fix_index(long i, size_t n) { // OBJ: 1-based, negative = relative to the end; -1 = absent, -2 = invalid
+    if (i > 0) return i - 1 < 0x7fffffffL ? (int)(i - 1) : 0x7fffffff; // range-checked against the arrays when the mesh is built
+    if (i < 0) return (long)n + i >= 0 ? (int)((long)n + i) : -2;
     return -1;
 }
 
@@ -289,6 +289,10 @@ Model::Model(const std::string& dir, const std::string& name) : modelDirectory(d
             std::array<vec2, 3> uv;
             for (int k = 0; k < 3; ++k) {
                 const Idx& ix = face[k];
+                // indices come from the file: a face may name a vertex / normal / texcoord that does not exist
+                if (ix.v < 0 || (size_t)ix.v >= V.size() / 3 || (ix.vn >= 0 && (size_t)ix.vn >= VN.size() / 3) ||
+                    (ix.vt >= 0 && (size_t)ix.vt >= VT.size() / 2))
+                    throw std::runtime_error("shape '" + sh.name + "': face index out of range");
                 vs[k] = vec3(V[3 * ix.v], V[3 * ix.v + 1], V[3 * ix.v + 2]);
                 ns[k] = ix.vn >= 0 ? vec3(VN[3 * ix.vn], VN[3 * ix.vn + 1], VN[3 * ix.vn + 2]) : vec3(0, 0, 0);
                 uv[k] = ix.vt >= 0 ? vec2(VT[2 * ix.vt], VT[2 * ix.vt + 1]) : vec2(0, 0);

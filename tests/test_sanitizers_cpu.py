@@ -86,3 +86,35 @@ def test_host_scene_preparation_under_sanitizers(tmp_path):
     r = subprocess.run([exe], capture_output=True, env=ENV, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:] + r.stdout.decode()
     assert r.stdout.decode().count(" ok") == 5
+
+
+def test_obj_mtl_xml_loader_survives_corrupted_files(tmp_path):
+    """The OBJ/MTL/XML loader (pooraytracer_amd/host/model.cpp, Camera::SetViewParametersByXmlFile) parses text it
+    did not write: under ASan/UBSan it must either load or throw on mangled input, never crash or read out of
+    bounds.  Links the (uninstrumented) libprt_hip.so only to resolve symbols; no device call is made."""
+    from pooraytracer_amd import build, scenes
+    build.build_host_example()
+    exe = str(tmp_path / "model_san")
+    host = os.path.join(ROOT, "pooraytracer_amd", "host")
+    lib_dir = os.path.dirname(build.LIB)
+    subprocess.check_call(["g++"] + SAN + ["-pthread", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "model_sanitize.cpp")] +
+                          [os.path.join(host, f) for f in ("model.cpp", "host_api.cpp", "png_decode.cpp", "jpeg_decode.cpp")] +
+                          ["-L", lib_dir, "-Wl,-rpath," + lib_dir, "-lprt_hip", "-o", exe])
+    data = scenes.mixed_materials(16, 16)
+    res = tmp_path / "res"
+    scenes.export_obj(data, str(res), texture_format="png")
+    d = res / data.name
+    ok = subprocess.run([exe, str(d), data.name], capture_output=True, env=ENV, timeout=120)
+    assert ok.returncode == 0, ok.stderr.decode()[-3000:] + ok.stdout.decode()
+    rng = np.random.default_rng(7)
+    outcomes = {0: 0, 1: 0}
+    for ext in ("obj", "mtl", "xml"):
+        path = d / f"{data.name}.{ext}"
+        good = path.read_bytes()
+        for bad in _corruptions(good, rng, 60):
+            path.write_bytes(bad)
+            r = subprocess.run([exe, str(d), data.name], capture_output=True, env=ENV, timeout=120)
+            assert r.returncode in (0, 1), (ext, r.returncode, r.stderr.decode()[-3000:])
+            outcomes[r.returncode] += 1
+        path.write_bytes(good)
+    assert outcomes[0] > 10 and outcomes[1] > 10
