@@ -38,7 +38,7 @@ extern "C" {
 
 /* error codes */
 #define PRT_OK 0
-#define PRT_E_INVALID (-1)    /* bad argument / inconsistent scene description */
+#define PRT_E_INVALID (-1)    /* bad argument / inconsistent scene description / non-finite vertex coordinate */
 #define PRT_E_NO_DEVICE (-2)  /* no HIP device visible */
 #define PRT_E_HIP (-3)        /* a HIP runtime call failed (message has the HIP error string) */
 #define PRT_E_OOM (-4)        /* host or device allocation failed */

@@ -152,6 +152,9 @@ int prt_scene_create(const PrtSceneDesc* desc, PrtScene** out) {
             return fail(PRT_E_INVALID, "prt_scene_create: unknown material type");
         if (m.texture >= (int32_t)desc->n_textures) return fail(PRT_E_INVALID, "prt_scene_create: texture index out of range");
     }
+    // NaN / infinite coordinates have no place in a BVH (the builders' orderings would be inconsistent)
+    for (uint64_t i = 0; i < desc->n_tris * 9; ++i)
+        if (!std::isfinite(desc->vertices[i])) return fail(PRT_E_INVALID, "prt_scene_create: vertex coordinate is not finite");
     PrtScene* s = new (std::nothrow) PrtScene();
     if (!s) return fail(PRT_E_OOM, "prt_scene_create: out of host memory");
     try {
@@ -394,6 +397,8 @@ int prt_scene_upload(PrtScene* s, int device) {
 
 int prt_scene_update_vertices(PrtScene* s, const double* vertices, const double* normals) {
     if (!s || (!vertices && !s->tris.empty())) return fail(PRT_E_INVALID, "prt_scene_update_vertices: null argument");
+    for (size_t i = 0; i < s->tris.size() * 9; ++i)
+        if (!std::isfinite(vertices[i])) return fail(PRT_E_INVALID, "prt_scene_update_vertices: vertex coordinate is not finite");
     try {
         prt::update_triangles(vertices, normals, s->tris);
         PrtSceneDesc d;

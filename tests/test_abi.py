@@ -93,6 +93,22 @@ def test_scene_create_rejects_bad_input(prt_lib):
     assert e.value.code == _abi.PRT_E_INVALID
 
 
+def test_scene_create_rejects_non_finite_vertices(prt_lib):
+    for bad in (np.nan, np.inf, -np.inf):
+        data = scenes.tiny_scene()
+        data.vertices = data.vertices.copy()
+        data.vertices[3, 1, 2] = bad
+        with pytest.raises(api.PrtError) as e:
+            api.Scene(data)
+        assert e.value.code == _abi.PRT_E_INVALID
+    sc = api.Scene(scenes.tiny_scene())
+    v = scenes.tiny_scene().vertices.copy()
+    v[0, 0, 0] = np.nan
+    with pytest.raises(api.PrtError):
+        sc.update_vertices(v)
+    sc.close()
+
+
 def test_product_does_not_import_oracle():
     """The product package and C sources must never reference the oracle."""
     pkg = os.path.join(ROOT, "pooraytracer_amd")
