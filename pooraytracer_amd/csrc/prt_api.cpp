@@ -154,7 +154,8 @@ int prt_scene_create(const PrtSceneDesc* desc, PrtScene** out) {
     }
     // NaN / infinite coordinates have no place in a BVH (the builders' orderings would be inconsistent)
     for (uint64_t i = 0; i < desc->n_tris * 9; ++i)
-        if (!std::isfinite(desc->vertices[i])) return fail(PRT_E_INVALID, "prt_scene_create: vertex coordinate is not finite");
+        if (!(std::fabs(desc->vertices[i]) <= 1e18)) // also catches NaN; the fp32 box tests need headroom below FLT_MAX
+            return fail(PRT_E_INVALID, "prt_scene_create: vertex coordinate is not finite (or beyond 1e18)");
     PrtScene* s = new (std::nothrow) PrtScene();
     if (!s) return fail(PRT_E_OOM, "prt_scene_create: out of host memory");
     try {
@@ -398,7 +399,7 @@ int prt_scene_upload(PrtScene* s, int device) {
 int prt_scene_update_vertices(PrtScene* s, const double* vertices, const double* normals) {
     if (!s || (!vertices && !s->tris.empty())) return fail(PRT_E_INVALID, "prt_scene_update_vertices: null argument");
     for (size_t i = 0; i < s->tris.size() * 9; ++i)
-        if (!std::isfinite(vertices[i])) return fail(PRT_E_INVALID, "prt_scene_update_vertices: vertex coordinate is not finite");
+        if (!(std::fabs(vertices[i]) <= 1e18)) return fail(PRT_E_INVALID, "prt_scene_update_vertices: vertex coordinate is not finite (or beyond 1e18)");
     try {
         prt::update_triangles(vertices, normals, s->tris);
         PrtSceneDesc d;

@@ -94,7 +94,7 @@ def test_scene_create_rejects_bad_input(prt_lib):
 
 
 def test_scene_create_rejects_non_finite_vertices(prt_lib):
-    for bad in (np.nan, np.inf, -np.inf):
+    for bad in (np.nan, np.inf, -np.inf, 1e300):
         data = scenes.tiny_scene()
         data.vertices = data.vertices.copy()
         data.vertices[3, 1, 2] = bad
