@@ -450,3 +450,39 @@ def test_lds_tables_and_plain_kernels_agree(gpu, monkeypatch):
     monkeypatch.delenv("PRT_TUNE_NO_LDS", raising=False)
     cpu, _ = oracle.Oracle(many).render(spp=4, max_depth=8, seed=11, nthreads=8)
     compare_images(api.Scene(many).upload(gpu).render(spp=4, max_depth=8, seed=11), cpu)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale,offset", [(1e-4, (0.0, 0.0, 0.0)), (1.0, (4.0e4, -2.5e4, 1.0e4)), (3.0e3, (1.0e6, 2.0e6, -3.0e6))])
+def test_scaled_and_translated_scene_hits(gpu, scale, offset):
+    """The fp32 box tests work on a 16-bit grid over the scene bounds with a per-ray pad proportional to
+    |origin| + scene extent: they must stay conservative when the scene is tiny, far from the origin, or large
+    and far (fp32 has 24 bits; at 3e6 one ulp is 0.25).  Closest hits against the CPU oracle, which knows no
+    boxes' rounding (fp64 slabs)."""
+    import copy
+    base = scenes.cornell_box(ball_subdiv=3, width=32, height=32)
+    data = copy.copy(base)
+    off = np.asarray(offset)
+    data.vertices = base.vertices * scale + off
+    sc = api.Scene(data).upload(gpu)
+    orc = oracle.Oracle(data)
+    lo, hi = data.vertices.reshape(-1, 3).min(0), data.vertices.reshape(-1, 3).max(0)
+    rays = scenes.random_rays(100_000, lo, hi, seed=31)
+    rays["tmin"] = 1e-4 * scale
+    b = orc.trace_closest(rays)
+    # far from the origin t = (D - n.o)/(n.d) cancels ~|o| digits, and the GPU forms FMAs where the oracle does not:
+    # the fp64 results agree to |o| * eps rather than to 1e-12; a box that culled wrongly would instead show up
+    # as a miss or as a farther triangle, i.e. a difference of the order of the scene
+    mag = float(np.abs(data.vertices).max())
+    tol = 64 * np.finfo(np.float64).eps * mag * 1e3 + 1e-12
+
+    def check(g):
+        assert np.array_equal(g["prim"] >= 0, b["prim"] >= 0)
+        hit = b["prim"] >= 0
+        assert np.all(np.abs(g["t"][hit] - b["t"][hit]) <= tol * np.maximum(1.0, b["t"][hit]))
+        diff = hit & (g["prim"] != b["prim"])
+        assert diff.mean() < 1e-3  # ties within rounding on shared edges only
+
+    check(sc.trace_closest(rays))
+    # the device-built tree obeys the same bounds
+    check(api.Scene(data, device_bvh=True).upload(gpu).trace_closest(rays))
