@@ -387,20 +387,28 @@ PRT_DEV d3 tex_value(const DScene& S, int ti, double u, double v) {
 }
 
 // ------------------------------------------------------------------ samplers (RandomNumberGenerator.h:39-73)
+// sin and cos for |x| <= pi/4: the kernel polynomials of fdlibm (k_sin.c / k_cos.c, < 1 ulp), without the range
+// reduction a general sincos() carries.  The concentric map only ever needs this range.
+PRT_DEV void sincos_quarter(double x, double& sn, double& cs) {
+    const double z = x * x;
+    const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                      z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    sn = x + (x * z) * (-1.66666666666666324348e-01 + z * ps);
+    const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    cs = 1.0 - (0.5 * z - z * pc);
+}
 PRT_DEV d2 disk_concentric(d2 u) {
     d2 off = {2. * u.x - 1., 2. * u.y - 1.};
     if (off.x == 0. && off.y == 0.) return {0., 0.};
-    double theta, r;
-    if (fabs(off.x) > fabs(off.y)) {
-        r = off.x;
-        theta = PRT_PI_OVER_4 * (off.y / off.x);
-    } else {
-        r = off.y;
-        theta = PRT_PI_OVER_2 - PRT_PI_OVER_4 * (off.x / off.y);
-    }
+    // RandomNumberGenerator.h:39-56: theta = pi/4 * (y/x), or pi/2 - pi/4 * (x/y) — i.e. sin and cos swapped
     double sn, cs;
-    sincos(theta, &sn, &cs);
-    return {r * cs, r * sn};
+    if (fabs(off.x) > fabs(off.y)) {
+        sincos_quarter(PRT_PI_OVER_4 * (off.y / off.x), sn, cs);
+        return {off.x * cs, off.x * sn};
+    }
+    sincos_quarter(PRT_PI_OVER_4 * (off.x / off.y), cs, sn); // cos(pi/2 - phi) = sin(phi), sin(pi/2 - phi) = cos(phi)
+    return {off.y * cs, off.y * sn};
 }
 // SampleCosineHemisphere: glm::dvec2(RandomDouble(), RandomDouble()) as compiled by g++ (right-to-left):
 // u.y = first draw, u.x = second draw.
