@@ -398,6 +398,17 @@ PRT_DEV void sincos_quarter(double x, double& sn, double& cs) {
                       z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
     cs = 1.0 - (0.5 * z - z * pc);
 }
+// sin and cos of 2*pi*u for u in [0,1): the quarter turn nearest to u is subtracted exactly, the remainder
+// (|r| <= 1/8, i.e. |angle| <= pi/4) goes through the kernel polynomials, the quadrant swaps / negates.
+PRT_DEV void sincos_turns(double u, double& sn, double& cs) {
+    const double k = floor(4.0 * u + 0.5);     // 0..4
+    const double r = u - 0.25 * k;             // exact
+    double s, c;
+    sincos_quarter(2.0 * PRT_PI * r, s, c);
+    const int q = (int)k & 3;
+    sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+}
 PRT_DEV d2 disk_concentric(d2 u) {
     d2 off = {2. * u.x - 1., 2. * u.y - 1.};
     if (off.x == 0. && off.y == 0.) return {0., 0.};
@@ -605,11 +616,13 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
             fr = mat_kd<FEAT>(S, m, uv) * PRT_INV_PI;
         } else if (m.pkd <= u && u < m.pkd + m.pks) {
             double u1 = rng.next(), u2 = rng.next();
-            double alpha = acos(pow_pos(u1, 1.0 / (m.ns + 1.0)));
-            double phi = 2.0 * PRT_PI * u2;
+            // alpha = acos(u1^(1/(Ns+1))), phi = 2 pi u2 (Material.h:205-208): cos(alpha) IS the power, sin(alpha)
+            // its Pythagorean complement, and sin/cos(2 pi u2) reduce exactly in u2 to a quarter-period polynomial —
+            // no acos, no general-range sincos (their results differ from these by rounding only)
             double sa, ca, sp, cp;
-            sincos(alpha, &sa, &ca);
-            sincos(phi, &sp, &cp);
+            ca = fmin(pow_pos(u1, 1.0 / (m.ns + 1.0)), 1.0);
+            sa = sqrt(fmax(0.0, 1.0 - ca * ca));
+            sincos_turns(u2, sp, cp);
             d3 rw = mk3(sa * cp, sa * sp, ca);
             // ReflectiveSpaceToLocal, Material.h:299-311
             d3 lr = normalize(reflect_z(wo));
