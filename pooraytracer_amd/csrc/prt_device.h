@@ -631,10 +631,12 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
             d3 B = cross(lr, T);
             wi = rw.x * T + rw.y * B + rw.z * lr;
             // SpecularPDF, Material.h:255-261
-            if (wi.z <= 0.) pdf = 0.0;
-            else pdf = (m.ns + 1.0) * PRT_INV_2PI * pow_pos(dot(wi, lr), m.ns);
-            double lca = fmax(0.0, dot(wi, lr));
-            if (wi.z > 0. && lca > 0.) fr = mat_ks<FEAT>(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pow_pos(lca, m.ns);
+            // both the pdf and f use cos^Ns of the angle to the mirror direction: one pow, evaluated only where used
+            const double dl = dot(wi, lr);
+            const double lca = fmax(0.0, dl);
+            const double pw = wi.z > 0. ? pow_pos(dl, m.ns) : 0.0;
+            pdf = wi.z <= 0. ? 0.0 : (m.ns + 1.0) * PRT_INV_2PI * pw;
+            if (wi.z > 0. && lca > 0.) fr = mat_ks<FEAT>(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pw;
         }
         wi_world = local_to_world(wi, f);
         if (pdf > 0. && wi.z > 0) att = fr * wi.z / pdf;
