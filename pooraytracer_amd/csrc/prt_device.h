@@ -591,7 +591,7 @@ PRT_DEV d3 mat_eval(const DScene& S, const DMaterial& m, d3 wi, d3 wo, d2 uv, Rn
 // direction, `att` = f * cos / pdf.  rd = incoming ray direction (unnormalised for camera rays).
 template <int FEAT>
 PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame& f, d2 uv, Rng& rng, d3& att,
-                         d3& wi_world) {
+                         d3& wi_world, bool have_fr = false, d3 fr_pre = d3{0., 0., 0.}) {
     if (!(FEAT & PRT_FEAT_PHONG) && m.type == 1) return false; // not reachable: the host picks a permutation that
     if (!(FEAT & PRT_FEAT_CT) && m.type == 3) return false;    // covers every material type of the scene
     switch (m.type) {
@@ -599,7 +599,8 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
         d3 wi = cosine_hemisphere(rng);
         while (wi.z <= 0.) wi = cosine_hemisphere(rng);
         double pdf = wi.z * PRT_INV_PI;
-        d3 fr = mat_kd<FEAT>(S, m, uv) * PRT_INV_PI;
+        // textured surfaces: the light evaluation of this vertex (same pass) has already looked the albedo up
+        d3 fr = ((FEAT & PRT_FEAT_TEX) && have_fr) ? fr_pre : mat_kd<FEAT>(S, m, uv) * PRT_INV_PI;
         wi_world = local_to_world(wi, f);
         att = (fr * wi.z) * (1.0 / pdf); // fr*cos/pdf with one reciprocal (last-bit rounding only)
         return true;

@@ -288,6 +288,8 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
             d3 pos = tr.o;                 // shading point (ST_SHADOW: the shadow ray's origin)
             d3 shadow_dir = mk3(0, 0, 1);
             HitInfo sh;
+            bool have_fr = false;
+            d3 fr_seen = mk3(0, 0, 0);
             if (state == ST_CLOSEST) {
                 const HitInfo h = tr.hit;
                 if (h.tri < 0) {
@@ -357,6 +359,10 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     const d3 lwi = world_to_local(td, c.f);
                     const d3 lln = world_to_local(ln, c.f);
                     const d3 fr = mat_eval<FEAT>(S, m, lwi, wo, c.uv, rng);
+                    if (FEAT & PRT_FEAT_TEX) {
+                        have_fr = m.type == 0; // Lambertian: Eval returned albedo / pi, which Scatter needs again
+                        fr_seen = fr;
+                    }
                     const double cosT = lwi.z;
                     const double cosTB = dot(lln, -lwi);
                     // Camera.cpp:172: emission*fr*cosT*cosTB/dist^2/pdf, the scalar factor folded into one division
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     const ShadeCtx c = make_ctx<FEAT>(S, pos, rd, sh);
                     const DMaterial& m = MATERIAL(c.material);
                     d3 att, wi;
-                    if (mat_scatter<FEAT>(S, m, rd, c.f, c.uv, rng, att, wi)) {
+                    if (mat_scatter<FEAT>(S, m, rd, c.f, c.uv, rng, att, wi, have_fr, fr_seen)) {
                         depth--; // RayColor(scattered, depth-1): returns 0 when depth-1 < 0
                         if (depth >= 0) {
                             const d3 beta = (PST_LD(S_BETA) * att) * P.inv_rr;
