@@ -525,7 +525,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.rr = p->russian_roulette;
     P.inv_rr = 1.0 / p->russian_roulette;
     // wave scheduling thresholds (developer overrides through the environment for sweeps)
-    P.keep = s->feat == 0 ? 24 : 16; // measured optima at the BASELINE spp (lean: 20-28 flat; others: 16)
+    P.keep = s->feat == 0 ? 24 : s->feat == 2 ? 20 : 16; // measured optima at the BASELINE spp (lean 24, Phong 20, textured / all 16)
     P.leaf_batch = 32;
     P.inner_min = 12;
     if (const char* e = std::getenv("PRT_TUNE_KEEP")) P.keep = std::atoi(e);
