@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 1
+#define PRT_ABI_VERSION 2
 
 /* error codes */
 #define PRT_OK 0
@@ -152,8 +152,8 @@ typedef struct PrtLightSample {
 typedef struct PrtCounters {
     uint64_t rays_closest;  /* camera + continuation traversals */
     uint64_t rays_shadow;   /* NEE visibility traversals */
-    uint64_t node_fetches;  /* 32-byte BVH node records read (counting runs only) */
-    uint64_t tri_tests;     /* 128-byte triangle records tested (counting runs only) */
+    uint64_t node_fetches;  /* BVH node records read (counting runs only; PrtBvhInfo.node_bytes each) */
+    uint64_t tri_tests;     /* triangle plane / interval tests = first 64 bytes of a 128-byte record (counting runs only) */
     uint64_t samples;       /* camera samples started */
     double kernel_ms;       /* hipEvent time of the dominant kernel of the last call */
     uint64_t bvh_nodes;     /* static: nodes in the flattened tree */
@@ -161,6 +161,7 @@ typedef struct PrtCounters {
     uint64_t inner_rounds;  /* counting runs: wave-level node-visit rounds (64 lanes each) */
     uint64_t leaf_rounds;   /* counting runs: wave-level leaf rounds */
     uint64_t refills;       /* counting runs: wave-level shade/refill passes */
+    uint64_t tri_full;      /* counting runs: tests that passed the interval check and fetched the second 64 bytes */
 } PrtCounters;
 
 /* Which builder made the traversal BVH and what it cost. */
@@ -170,6 +171,8 @@ typedef struct PrtBvhInfo {
     uint32_t built_on_device;
     double build_ms;  /* host builder: wall time inside prt_scene_create; device builder: HIP-event time */
     double sort_ms, tree_ms, split_ms; /* device builder phases: Morton sort / box segment tree / SAH levels */
+    uint32_t node_bytes; /* size of one node record in HBM */
+    uint32_t width;      /* children per node */
 } PrtBvhInfo;
 
 typedef struct PrtScene PrtScene;

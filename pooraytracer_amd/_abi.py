@@ -5,7 +5,7 @@ tests/test_abi.py checks sizes and that every declared symbol is exported.
 """
 import ctypes as C
 
-PRT_ABI_VERSION = 1
+PRT_ABI_VERSION = 2
 
 PRT_OK = 0
 PRT_E_INVALID = -1
@@ -79,6 +79,8 @@ class PrtBvhInfo(C.Structure):
         ("sort_ms", C.c_double),
         ("tree_ms", C.c_double),
         ("split_ms", C.c_double),
+        ("node_bytes", C.c_uint32),
+        ("width", C.c_uint32),
     ]
 
 
@@ -148,6 +150,7 @@ class PrtCounters(C.Structure):
         ("inner_rounds", C.c_uint64),
         ("leaf_rounds", C.c_uint64),
         ("refills", C.c_uint64),
+        ("tri_full", C.c_uint64),
     ]
 
 

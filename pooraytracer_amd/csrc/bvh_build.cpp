@@ -8,10 +8,18 @@
 // outward (+ a small inflation that covers the rounding of the kernel's fma slab test) so the box
 // test can only ever cull conservatively — every hit accept/reject is the fp64 triangle test.
 // Depth is bounded so the per-lane LDS stack (PRT_STACK_DEPTH entries) cannot overflow.
+//
+// PRT_BVH_WIDTH 4: the same binary tree is then collapsed into 4-wide nodes (64 bytes: four child boxes + four
+// refs) — a node absorbs the child with the largest box, repeatedly, until it has four children — so a ray makes
+// about half as many dependent node fetches.  A traversal pushes up to three siblings per level, so the collapse
+// carries a stack budget down the tree: a node with k children leaves budget - (k-1) entries to each child's
+// subtree, and a child is only absorbed while every resulting child's binary subtree is no taller than what is
+// left for it (a binary subtree of height h needs at most h entries).  The root starts with PRT_STACK_DEPTH.
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <utility>
 
 #include "prt_host.h"
 
@@ -22,7 +30,7 @@ namespace {
 #define PRT_SAH_BINS 16
 #endif
 constexpr int kBins = PRT_SAH_BINS;
-constexpr int kMaxLevels = PRT_STACK_DEPTH - 2; // inner-node levels
+constexpr int kMaxLevels = PRT_BVH2_LEVELS; // inner-node levels of the binary tree
 #ifndef PRT_COST_TRI
 #define PRT_COST_TRI 1.5f
 #endif
@@ -221,6 +229,63 @@ void quant_grid(const float root_lo[3], const float root_hi[3], bool empty, floa
     }
 }
 
+// Structural check of a flattened tree (either builder, either width): every reference in range, every triangle
+// in exactly one leaf, no traversal able to need more than PRT_STACK_DEPTH stack entries.  Used on device-built
+// trees when PRT_VALIDATE_BVH is set (tests): a bad node index would be a GPU memory fault, not a wrong pixel.
+bool validate_nodes(const DNode* nodes, size_t n_nodes, size_t n_tris, std::string* err) {
+    auto bad = [&](const char* m) {
+        if (err) *err = m;
+        return false;
+    };
+    if (n_nodes == 0) return bad("no nodes");
+    std::vector<uint8_t> seen(n_tris, 0);
+    std::vector<int> need(n_nodes, -1);
+    // iterative post-order over node indices (children may have any index in a device-built tree)
+    std::vector<std::pair<uint32_t, int>> st;
+    st.push_back({0u, 0});
+    size_t visited = 0;
+    while (!st.empty()) {
+        auto [i, phase] = st.back();
+        st.pop_back();
+        int32_t refs[4];
+        int nr = 0;
+#if PRT_BVH_WIDTH == 4
+        for (int c = 0; c < 4; ++c)
+            if (nodes[i].ref[c] != (int32_t)0x80000000) refs[nr++] = nodes[i].ref[c];
+#else
+        refs[nr++] = nodes[i].ref0;
+        if (!(n_tris == 1 && nodes[i].ref1 == nodes[i].ref0)) refs[nr++] = nodes[i].ref1;
+#endif
+        if (phase == 0) {
+            if (++visited > n_nodes) return bad("cycle or shared node");
+            if (nr < 1) return bad("node without children");
+            st.push_back({i, 1});
+            for (int c = 0; c < nr; ++c) {
+                if (refs[c] >= 0) {
+                    if ((size_t)refs[c] >= n_nodes) return bad("node index out of range");
+                    if (need[refs[c]] != -1) return bad("node referenced twice");
+                    need[refs[c]] = -2;
+                    st.push_back({(uint32_t)refs[c], 0});
+                } else {
+                    const uint32_t enc = ~(uint32_t)refs[c], first = enc >> 3, cnt = (enc & 7u) + 1u;
+                    if (cnt > PRT_LEAF_MAX || (size_t)first + cnt > n_tris) return bad("leaf range out of bounds");
+                    for (uint32_t t = first; t < first + cnt; ++t)
+                        if (seen[t]++) return bad("triangle in two leaves");
+                }
+            }
+        } else {
+            int worst = 0;
+            for (int c = 0; c < nr; ++c)
+                if (refs[c] >= 0) worst = std::max(worst, need[refs[c]]);
+            need[i] = nr - 1 + worst;
+        }
+    }
+    for (size_t t = 0; t < n_tris; ++t)
+        if (!seen[t]) return bad("triangle in no leaf");
+    if (need[0] > PRT_STACK_DEPTH) return bad("a traversal could overflow the stack");
+    return true;
+}
+
 bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err) {
     out.nodes.clear();
     out.order.clear();
@@ -272,7 +337,9 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
     out.order.resize(n);
     for (size_t i = 0; i < n; ++i) out.order[i] = b.prims[i].idx;
 
+#if PRT_BVH_WIDTH != 4
     out.nodes.resize(fn.size());
+#endif
 #if PRT_NODE16
     // quantisation grid over the root box: coordinate(q) = g0 + q * gs, evaluated in double here; the
     // kernel's float evaluation error is covered by its per-ray pad.  lo rounds down, hi rounds up.
@@ -294,6 +361,95 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
         while (q < 65535 && g0[a] + q * gs[a] < (double)v) q += 1;
         return (uint16_t)q;
     };
+#if PRT_BVH_WIDTH == 4
+    {
+        // heights of the binary subtrees (children follow their parent in the pre-order array)
+        std::vector<uint8_t> h2(fn.size(), 1);
+        for (size_t i = fn.size(); i-- > 0;) {
+            const int a = fn[i].ref0 >= 0 ? h2[fn[i].ref0] : 0, c = fn[i].ref1 >= 0 ? h2[fn[i].ref1] : 0;
+            h2[i] = (uint8_t)(1 + std::max(a, c));
+        }
+        struct Kid {
+            int32_t ref; // ref in the BINARY tree (inner index or leaf ref)
+            float lo[3], hi[3];
+        };
+        auto kid_of = [&](const FNode& f, int side) {
+            Kid k;
+            k.ref = side ? f.ref1 : f.ref0;
+            const float* x = side ? f.c1x : f.c0x;
+            const float* y = side ? f.c1y : f.c0y;
+            const float* z = side ? f.c1z : f.c0z;
+            k.lo[0] = x[0]; k.hi[0] = x[1]; k.lo[1] = y[0]; k.hi[1] = y[1]; k.lo[2] = z[0]; k.hi[2] = z[1];
+            return k;
+        };
+        auto height = [&](int32_t ref) { return ref >= 0 ? (int)h2[ref] : 0; };
+        auto area = [](const Kid& k) {
+            const float dx = k.hi[0] - k.lo[0], dy = k.hi[1] - k.lo[1], dz = k.hi[2] - k.lo[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        struct Open {
+            int32_t bin;   // binary node to collapse
+            uint32_t slot; // index of the wide node it becomes
+            int budget;    // stack entries its subtree may use
+            uint32_t depth;
+        };
+        std::vector<Open> todo;
+        out.nodes.clear();
+        out.nodes.emplace_back();
+        todo.push_back({0, 0, PRT_STACK_DEPTH, 0});
+        uint32_t wide_depth = 0;
+        const bool single = n == 1; // the one-triangle root lists its leaf twice: keep one copy
+        while (!todo.empty()) {
+            const Open o = todo.back();
+            todo.pop_back();
+            wide_depth = std::max(wide_depth, o.depth);
+            Kid kids[4];
+            int nk = 0;
+            kids[nk++] = kid_of(fn[o.bin], 0);
+            if (!single) kids[nk++] = kid_of(fn[o.bin], 1);
+            while (nk < 4) {
+                int best = -1;
+                float best_area = -1.f;
+                for (int i = 0; i < nk; ++i) {
+                    if (kids[i].ref < 0) continue;
+                    // absorbing kids[i] makes nk+1 children; each of them keeps o.budget - nk entries
+                    const int left = o.budget - nk;
+                    bool fits = height(fn[kids[i].ref].ref0) <= left && height(fn[kids[i].ref].ref1) <= left;
+                    for (int j = 0; j < nk && fits; ++j)
+                        if (j != i && height(kids[j].ref) > left) fits = false;
+                    if (fits && area(kids[i]) > best_area) {
+                        best_area = area(kids[i]);
+                        best = i;
+                    }
+                }
+                if (best < 0) break;
+                const FNode& f = fn[kids[best].ref];
+                kids[best] = kid_of(f, 0);
+                kids[nk++] = kid_of(f, 1);
+            }
+            // the inner children get consecutive wide nodes (two per 128-byte line)
+            DNode d;
+            for (int i = 0; i < 4; ++i) {
+                d.bx[i] = d.by[i] = d.bz[i] = 0x0000ffffu; // lo = 0xffff, hi = 0: never hit
+                d.ref[i] = (int32_t)0x80000000;
+            }
+            for (int i = 0; i < nk; ++i) {
+                d.bx[i] = (uint32_t)qlo(kids[i].lo[0], 0) | ((uint32_t)qhi(kids[i].hi[0], 0) << 16);
+                d.by[i] = (uint32_t)qlo(kids[i].lo[1], 1) | ((uint32_t)qhi(kids[i].hi[1], 1) << 16);
+                d.bz[i] = (uint32_t)qlo(kids[i].lo[2], 2) | ((uint32_t)qhi(kids[i].hi[2], 2) << 16);
+                if (kids[i].ref < 0) d.ref[i] = kids[i].ref;
+                else {
+                    d.ref[i] = (int32_t)out.nodes.size();
+                    out.nodes.emplace_back();
+                }
+            }
+            for (int i = nk - 1; i >= 0; --i) // depth-first, first child next
+                if (kids[i].ref >= 0) todo.push_back({kids[i].ref, (uint32_t)d.ref[i], o.budget - (nk - 1), o.depth + 1});
+            out.nodes[o.slot] = d;
+        }
+        out.depth = wide_depth + 1;
+    }
+#else
     for (size_t i = 0; i < fn.size(); ++i) {
         const FNode& f = fn[i];
         DNode& d = out.nodes[i];
@@ -306,6 +462,7 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
         d.ref0 = f.ref0;
         d.ref1 = f.ref1;
     }
+#endif
     float gm = 0.f; // the dequantised coordinates can exceed the fp32 boxes by one grid step
     for (int a = 0; a < 3; ++a)
         gm = std::max(gm, std::max(std::fabs(out.grid_origin[a]), std::fabs((float)(g0[a] + 65535.0 * gs[a]))));

@@ -16,6 +16,8 @@
 //                             Nothing is ever re-partitioned, so a level is one launch; children are
 //                             appended to the next level's queue with wave-aggregated atomics.
 //   6. k_quantise             fp32 child boxes -> 16-bit grid indices, rounded outward
+//      (PRT_BVH_WIDTH 4: k_heights + k_collapse_level instead — the binary tree is collapsed top-down, one launch
+//       per wide level, with the same greedy largest-box rule and stack budget as bvh_build.cpp)
 // Results (hits, images) do not depend on which builder made the tree — only exact ties could, and the
 // child order is deterministic here as well; node *numbering* follows atomic arrival order.
 #include <hip/hip_runtime.h>
@@ -33,7 +35,7 @@
 namespace prt {
 namespace {
 
-constexpr int kMaxLevels = PRT_STACK_DEPTH - 2; // inner-node levels, as in bvh_build.cpp
+constexpr int kMaxLevels = PRT_BVH2_LEVELS;     // inner-node levels of the binary tree, as in bvh_build.cpp
 constexpr float kCostTri = 1.5f, kCostNode = 1.0f;
 constexpr int kCand = 15;                       // equal-count candidate positions per node
 constexpr uint32_t kNoParent = 0xffffffffu;
@@ -305,26 +307,113 @@ struct Grid {
     float origin[3], step[3];
 };
 
+__device__ inline uint16_t quant_lo(const Grid& g, float v, int a) {
+    const double g0 = (double)g.origin[a], gs = (double)g.step[a];
+    double q = floor(((double)v - g0) / gs);
+    q = fmin(65535.0, fmax(0.0, q));
+    while (q > 0 && g0 + q * gs > (double)v) q -= 1;
+    return (uint16_t)q;
+}
+__device__ inline uint16_t quant_hi(const Grid& g, float v, int a) {
+    const double g0 = (double)g.origin[a], gs = (double)g.step[a];
+    double q = ceil(((double)v - g0) / gs);
+    q = fmin(65535.0, fmax(0.0, q));
+    while (q < 65535 && g0 + q * gs < (double)v) q += 1;
+    return (uint16_t)q;
+}
+
+#if PRT_BVH_WIDTH == 4
+// Heights of the binary subtrees, one launch per level from the deepest up (nodes of one level are contiguous:
+// the split launches allocate them level by level).
+__global__ void k_heights(const FNodeD* __restrict__ fn, uint32_t first, uint32_t count, uint8_t* __restrict__ h2) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const FNodeD& f = fn[first + t];
+    const int a = f.ref[0] >= 0 ? h2[f.ref[0]] : 0, b = f.ref[1] >= 0 ? h2[f.ref[1]] : 0;
+    h2[first + t] = (uint8_t)(1 + max(a, b));
+}
+
+struct Open { // binary node `bin` becomes wide node `slot`; its subtree may use `budget` stack entries
+    int32_t bin;
+    uint32_t slot;
+    int32_t budget;
+};
+struct WideState {
+    uint32_t n_wide;
+    uint32_t depth;
+    uint32_t counts[kMaxLevels + 2]; // open nodes per wide level
+};
+
+// One level of the collapse (see bvh_build.cpp for the rule): every open binary node absorbs the child with the
+// largest box while the stack budget allows, up to four children; its inner children get consecutive wide slots.
+__global__ void k_collapse_level(const Open* __restrict__ in, Open* __restrict__ out, WideState* ws, int level,
+                                 const FNodeD* __restrict__ fn, const uint8_t* __restrict__ h2, Grid g, DNode* __restrict__ wide) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ws->counts[level]) return;
+    const Open o = in[t];
+    int32_t ref[4];
+    FBox box[4];
+    int nk = 2;
+    ref[0] = fn[o.bin].ref[0]; box[0] = fn[o.bin].c[0];
+    ref[1] = fn[o.bin].ref[1]; box[1] = fn[o.bin].c[1];
+    auto height = [&](int32_t r) { return r >= 0 ? (int)h2[r] : 0; };
+    while (nk < 4) {
+        int best = -1;
+        float best_area = -1.f;
+        const int left = o.budget - nk; // absorbing makes nk+1 children; each keeps budget - nk entries
+        for (int i = 0; i < nk; ++i) {
+            if (ref[i] < 0) continue;
+            bool fits = height(fn[ref[i]].ref[0]) <= left && height(fn[ref[i]].ref[1]) <= left;
+            for (int j = 0; j < nk && fits; ++j)
+                if (j != i && height(ref[j]) > left) fits = false;
+            const float a = half_area(box[i]);
+            if (fits && a > best_area) {
+                best_area = a;
+                best = i;
+            }
+        }
+        if (best < 0) break;
+        const FNodeD f = fn[ref[best]];
+        ref[best] = f.ref[0]; box[best] = f.c[0];
+        ref[nk] = f.ref[1]; box[nk] = f.c[1];
+        ++nk;
+    }
+    int n_inner = 0;
+    for (int i = 0; i < nk; ++i) n_inner += ref[i] >= 0;
+    uint32_t base = 0, qbase = 0;
+    if (n_inner) {
+        base = atomicAdd(&ws->n_wide, (uint32_t)n_inner);
+        qbase = atomicAdd(&ws->counts[level + 1], (uint32_t)n_inner);
+        atomicMax(&ws->depth, (uint32_t)level + 1u);
+    }
+    DNode d;
+    for (int i = 0; i < 4; ++i) {
+        d.bx[i] = d.by[i] = d.bz[i] = 0x0000ffffu;
+        d.ref[i] = (int32_t)0x80000000;
+    }
+    int k = 0;
+    for (int i = 0; i < nk; ++i) {
+        d.bx[i] = (uint32_t)quant_lo(g, box[i].lo[0], 0) | ((uint32_t)quant_hi(g, box[i].hi[0], 0) << 16);
+        d.by[i] = (uint32_t)quant_lo(g, box[i].lo[1], 1) | ((uint32_t)quant_hi(g, box[i].hi[1], 1) << 16);
+        d.bz[i] = (uint32_t)quant_lo(g, box[i].lo[2], 2) | ((uint32_t)quant_hi(g, box[i].hi[2], 2) << 16);
+        if (ref[i] < 0) d.ref[i] = ref[i];
+        else {
+            d.ref[i] = (int32_t)(base + k);
+            out[qbase + k] = Open{ref[i], base + (uint32_t)k, o.budget - (nk - 1)};
+            ++k;
+        }
+    }
+    wide[o.slot] = d;
+}
+#else
 __global__ void k_quantise(const FNodeD* __restrict__ fn, uint32_t n_nodes, Grid g, DNode* __restrict__ out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     const FNodeD f = fn[i];
     DNode d;
 #if PRT_NODE16
-    auto qlo = [&](float v, int a) -> uint16_t {
-        const double g0 = (double)g.origin[a], gs = (double)g.step[a];
-        double q = floor(((double)v - g0) / gs);
-        q = fmin(65535.0, fmax(0.0, q));
-        while (q > 0 && g0 + q * gs > (double)v) q -= 1;
-        return (uint16_t)q;
-    };
-    auto qhi = [&](float v, int a) -> uint16_t {
-        const double g0 = (double)g.origin[a], gs = (double)g.step[a];
-        double q = ceil(((double)v - g0) / gs);
-        q = fmin(65535.0, fmax(0.0, q));
-        while (q < 65535 && g0 + q * gs < (double)v) q += 1;
-        return (uint16_t)q;
-    };
+    auto qlo = [&](float v, int a) -> uint16_t { return quant_lo(g, v, a); };
+    auto qhi = [&](float v, int a) -> uint16_t { return quant_hi(g, v, a); };
     d.c0x[0] = qlo(f.c[0].lo[0], 0); d.c0x[1] = qhi(f.c[0].hi[0], 0);
     d.c0y[0] = qlo(f.c[0].lo[1], 1); d.c0y[1] = qhi(f.c[0].hi[1], 1);
     d.c0z[0] = qlo(f.c[0].lo[2], 2); d.c0z[1] = qhi(f.c[0].hi[2], 2);
@@ -344,6 +433,7 @@ __global__ void k_quantise(const FNodeD* __restrict__ fn, uint32_t n_nodes, Grid
     d.ref1 = f.ref[1];
     out[i] = d;
 }
+#endif // PRT_BVH_WIDTH
 
 struct Scratch { // frees every temporary on every exit path
     std::vector<void*> p;
@@ -493,6 +583,69 @@ bool build_bvh_device(const PrimBox* h_boxes, size_t n_, DeviceBVH& out, std::st
     Grid g;
     quant_grid(root_box.lo, root_box.hi, false, g.origin, g.step);
     DNode* d_nodes = nullptr;
+#if PRT_BVH_WIDTH == 4
+    uint32_t n_out = 0, out_depth = 0;
+    {
+        // binary nodes of level L occupy [first[L], first[L] + counts[L+1]/2): heights bottom-up, then the collapse
+        uint32_t first[kMaxLevels + 2], inner[kMaxLevels + 2];
+        uint32_t acc = 0;
+        for (int l = 0; l <= kMaxLevels; ++l) {
+            first[l] = acc;
+            inner[l] = hs.counts[l + 1] / 2;
+            acc += inner[l];
+        }
+        if (acc != hs.n_nodes) {
+            if (err) *err = "device BVH build: level ranges do not add up";
+            return false;
+        }
+        uint8_t* d_h2 = nullptr;
+        WideState* d_ws = nullptr;
+        Open *d_o0 = nullptr, *d_o1 = nullptr;
+        DNode* d_wide = nullptr;
+        BVH_HIP(tmp.alloc(&d_h2, hs.n_nodes));
+        BVH_HIP(tmp.alloc(&d_ws, 1));
+        BVH_HIP(tmp.alloc(&d_o0, hs.n_nodes));
+        BVH_HIP(tmp.alloc(&d_o1, hs.n_nodes));
+        BVH_HIP(tmp.alloc(&d_wide, hs.n_nodes)); // a wide node replaces at least one binary node
+        for (int l = kMaxLevels; l >= 0; --l)
+            if (inner[l]) k_heights<<<blocks(inner[l]), B, 0, st>>>(d_fn, first[l], inner[l], d_h2);
+        WideState ws0;
+        std::memset(&ws0, 0, sizeof(ws0));
+        ws0.n_wide = 1;
+        ws0.counts[0] = 1;
+        const Open root_open{0, 0, PRT_STACK_DEPTH};
+        BVH_HIP(hipMemcpyAsync(d_ws, &ws0, sizeof(ws0), hipMemcpyHostToDevice, st));
+        BVH_HIP(hipMemcpyAsync(d_o0, &root_open, sizeof(root_open), hipMemcpyHostToDevice, st));
+        Open *oin = d_o0, *oout = d_o1;
+        for (int level = 0; level <= kMaxLevels; ++level) {
+            uint64_t cap = 1;
+            for (int i = 0; i < level && cap < hs.n_nodes; ++i) cap *= 4;
+            cap = std::min<uint64_t>(cap, hs.n_nodes);
+            k_collapse_level<<<blocks(cap), B, 0, st>>>(oin, oout, d_ws, level, d_fn, d_h2, g, d_wide);
+            std::swap(oin, oout);
+        }
+        BVH_HIP(hipGetLastError());
+        WideState hw;
+        BVH_HIP(hipMemcpy(&hw, d_ws, sizeof(hw), hipMemcpyDeviceToHost));
+        if (hw.n_wide == 0 || hw.n_wide > hs.n_nodes || hw.counts[kMaxLevels + 1] != 0) {
+            if (err) *err = "device BVH build: inconsistent wide node count";
+            return false;
+        }
+        n_out = hw.n_wide;
+        out_depth = hw.depth + 1;
+        BVH_HIP(hipMalloc(reinterpret_cast<void**>(&d_nodes), std::max<size_t>((size_t)n_out * sizeof(DNode), 256)));
+        hipError_t e = hipMemcpyAsync(d_nodes, d_wide, (size_t)n_out * sizeof(DNode), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipEventRecord(ev[4], st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            (void)hipFree(d_nodes);
+            if (err) *err = std::string("device BVH build: ") + hipGetErrorString(e);
+            return false;
+        }
+    }
+    hs.n_nodes = n_out;
+    hs.depth = out_depth;
+#else
     BVH_HIP(hipMalloc(reinterpret_cast<void**>(&d_nodes), std::max<size_t>((size_t)hs.n_nodes * sizeof(DNode), 256)));
     k_quantise<<<blocks(hs.n_nodes), B, 0, st>>>(d_fn, hs.n_nodes, g, d_nodes);
     hipError_t e = hipGetLastError();
@@ -503,6 +656,7 @@ bool build_bvh_device(const PrimBox* h_boxes, size_t n_, DeviceBVH& out, std::st
         if (err) *err = std::string("device BVH build: ") + hipGetErrorString(e);
         return false;
     }
+#endif
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev[0], ev[1]); out.ms_sort = ms;
     (void)hipEventElapsedTime(&ms, ev[1], ev[2]); out.ms_tree = ms;

@@ -77,15 +77,27 @@ struct PrtScene {
         double* d_partial = nullptr;
         size_t partial_cap = 0;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        hipEvent_t done = nullptr; // recorded behind the last kernel of the call that used this slot
         bool timed = false;
         bool counted = false;
     };
     CallSlot slots[2];
     int cur = 0; // slot of the most recent call (prt_get_counters reads it)
+    // Next slot for an asynchronous call on `st`.  A slot may still be in use by a call issued two calls ago on
+    // another stream (three streams, or a trace call between two pipelined renders): its counters and partial
+    // sums must not be reset under a running kernel, so the new call's stream first waits for that call's end.
+    CallSlot* next_slot(hipStream_t st, hipError_t* err) {
+        cur ^= 1;
+        CallSlot& q = slots[cur];
+        *err = q.timed ? hipStreamWaitEvent(st, q.done, 0) : hipSuccess;
+        return &q;
+    }
     PrtCounters last{};
 
+    int fail_upload_at = -1, n_uploads = 0; // test hook (PRT_TEST_FAIL_UPLOAD=k): the k-th table upload reports out-of-memory
     template <typename T>
     int up(const std::vector<T>& v, const T** out) {
+        if (n_uploads++ == fail_upload_at) return fail(PRT_E_OOM, "prt_scene_upload: injected allocation failure (PRT_TEST_FAIL_UPLOAD)");
         void* p = nullptr;
         size_t bytes = std::max<size_t>(v.size() * sizeof(T), 256);
         PRT_HIP(hipMalloc(&p, bytes));
@@ -103,6 +115,7 @@ struct PrtScene {
             if (q.d_partial) (void)hipFree(q.d_partial);
             if (q.ev0) (void)hipEventDestroy(q.ev0);
             if (q.ev1) (void)hipEventDestroy(q.ev1);
+            if (q.done) (void)hipEventDestroy(q.done);
             q = CallSlot();
         }
         device = -1;
@@ -229,6 +242,8 @@ void prt_scene_destroy(PrtScene* s) {
 int prt_scene_bvh_info(const PrtScene* s, PrtBvhInfo* out) {
     if (!s || !out) return fail(PRT_E_INVALID, "prt_scene_bvh_info: null argument");
     *out = s->bvh_info;
+    out->node_bytes = (uint32_t)sizeof(DNode);
+    out->width = PRT_BVH_WIDTH;
     return PRT_OK;
 }
 
@@ -245,14 +260,31 @@ int prt_scene_light_order(const PrtScene* s, int32_t* prims, uint64_t cap) {
     return PRT_OK;
 }
 
+static int upload_impl(PrtScene* s, int device);
+
+// Either the whole scene is resident afterwards, or nothing is: a failure anywhere (allocation, copy, device build)
+// releases what was uploaded so far and leaves the scene in the not-uploaded state (device = -1), so that no later
+// call can launch a kernel on a half-filled DScene.
 int prt_scene_upload(PrtScene* s, int device) {
     if (!s) return fail(PRT_E_INVALID, "prt_scene_upload: null scene");
+    const int rc = upload_impl(s, device);
+    if (rc != PRT_OK) {
+        const std::string keep = g_err;
+        s->release();
+        g_err = keep;
+    }
+    return rc;
+}
+
+static int upload_impl(PrtScene* s, int device) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(PRT_E_NO_DEVICE, "prt_scene_upload: no HIP device");
     if (device < 0 || device >= ndev) return fail(PRT_E_INVALID, "prt_scene_upload: device index out of range");
     s->release();
     PRT_HIP(hipSetDevice(device));
     s->device = device;
+    s->n_uploads = 0;
+    s->fail_upload_at = std::getenv("PRT_TEST_FAIL_UPLOAD") ? std::atoi(std::getenv("PRT_TEST_FAIL_UPLOAD")) : -1;
     hipDeviceProp_t prop;
     PRT_HIP(hipGetDeviceProperties(&prop, device));
     s->n_cu = prop.multiProcessorCount;
@@ -290,6 +322,14 @@ int prt_scene_upload(PrtScene* s, int device) {
         if (!prt::build_bvh_device(pb.data(), n, db, &err)) return fail(PRT_E_HIP, "prt_scene_upload: " + err);
         s->allocs.push_back(db.d_nodes);
         d.nodes = db.d_nodes;
+        if (std::getenv("PRT_VALIDATE_BVH")) { // tests: check the device-built tree on the host before any ray visits it
+            std::vector<DNode> hn(db.n_nodes);
+            PRT_HIP(hipMemcpy(hn.data(), db.d_nodes, (size_t)db.n_nodes * sizeof(DNode), hipMemcpyDeviceToHost));
+            if (!prt::validate_nodes(hn.data(), hn.size(), n, &err)) {
+                (void)hipFree(db.d_order);
+                return fail(PRT_E_LIMIT, "prt_scene_upload: device-built BVH is malformed: " + err);
+            }
+        }
         // records go up in description order and are permuted into BVH leaf order in HBM
         const DTri* t_in = nullptr;
         const DTriShade* s_in = nullptr;
@@ -358,6 +398,7 @@ int prt_scene_upload(PrtScene* s, int device) {
         PRT_HIP(hipMemset(q.d_ctr, 0, sizeof(DCounters)));
         PRT_HIP(hipEventCreate(&q.ev0));
         PRT_HIP(hipEventCreate(&q.ev1));
+        PRT_HIP(hipEventCreateWithFlags(&q.done, hipEventDisableTiming));
     }
     s->feat = 0;
     for (const DMaterial& m : s->mats) {
@@ -440,14 +481,16 @@ int prt_trace_closest_device(PrtScene* s, const void* d_rays, size_t n, void* d_
     if (rc) return rc;
     if (n && (!d_rays || !d_hits)) return fail(PRT_E_INVALID, "prt_trace_closest_device: null buffer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    s->cur ^= 1;
-    PrtScene::CallSlot& q = s->slots[s->cur];
+    hipError_t we;
+    PrtScene::CallSlot& q = *s->next_slot(st, &we);
+    PRT_HIP(we);
     PRT_HIP(hipMemsetAsync(q.d_ctr, 0, sizeof(DCounters), st));
     PRT_HIP(hipEventRecord(q.ev0, st));
     prt::launch_trace(s->d, static_cast<const PrtRay*>(d_rays), n, static_cast<PrtHit*>(d_hits), q.d_ctr, count_work != 0,
                       s->n_cu, st);
     PRT_HIP(hipGetLastError());
     PRT_HIP(hipEventRecord(q.ev1, st));
+    PRT_HIP(hipEventRecord(q.done, st));
     q.timed = true;
     q.counted = count_work != 0;
     return PRT_OK;
@@ -606,8 +649,9 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.n_items = P.items_per_chunk * (uint64_t)chunks;
 
     const size_t need = std::max<size_t>(P.n_items * 3, 3);
-    s->cur ^= 1;
-    PrtScene::CallSlot& q = s->slots[s->cur];
+    hipError_t we;
+    PrtScene::CallSlot& q = *s->next_slot(st, &we);
+    PRT_HIP(we);
     if (need > q.partial_cap) {
         if (q.d_partial) (void)hipFree(q.d_partial); // hipFree waits for the device: nothing in flight reads it
         q.d_partial = nullptr;
@@ -620,6 +664,8 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     if (d_rgb_f64) PRT_HIP(hipMemsetAsync(d_rgb_f64, 0, npx * sizeof(double), st));
     if (d_rgb_f32) PRT_HIP(hipMemsetAsync(d_rgb_f32, 0, npx * sizeof(float), st));
     PRT_HIP(hipEventRecord(q.ev0, st));
+    // maxDepth < 0: RayColor returns 0 before it traces anything (Camera.cpp:121) — the cleared framebuffer is the frame
+    if (P.max_depth < 0) P.n_items = 0;
     if (P.n_items) {
         const uint64_t want = (P.n_items + PRT_BLOCK - 1) / PRT_BLOCK;
         const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)s->n_cu * bpc));
@@ -631,6 +677,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
         prt::launch_finalize(C, P, q.d_partial, static_cast<double*>(d_rgb_f64), static_cast<float*>(d_rgb_f32), st);
         PRT_HIP(hipGetLastError());
     }
+    PRT_HIP(hipEventRecord(q.done, st));
     q.timed = true;
     q.counted = count;
     return PRT_OK;
@@ -667,8 +714,8 @@ int prt_render(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* p, doub
 int prt_get_counters(PrtScene* s, PrtCounters* out) {
     if (!s || !out) return fail(PRT_E_INVALID, "prt_get_counters: null argument");
     PrtCounters c = s->last;
-    c.bvh_nodes = s->bvh.nodes.size();
-    c.bvh_depth = s->bvh.depth;
+    c.bvh_nodes = s->bvh_info.n_nodes; // host- and device-built trees alike (bvh.nodes is empty for the latter)
+    c.bvh_depth = s->bvh_info.depth;
     PrtScene::CallSlot& q = s->slots[s->cur];
     if (s->device >= 0 && q.timed) {
         PRT_HIP(hipSetDevice(s->device));
@@ -685,6 +732,7 @@ int prt_get_counters(PrtScene* s, PrtCounters* out) {
         c.inner_rounds = h.inner_rounds;
         c.leaf_rounds = h.leaf_rounds;
         c.refills = h.refills;
+        c.tri_full = h.tri_full;
         c.kernel_ms = ms;
     }
     s->last = c;

@@ -1,8 +1,8 @@
 // prt_device.h — device functions of the gfx950 path tracer (wave64, fp64 arithmetic).
 //
 // Everything here is written for CDNA4 directly: per-lane BVH2 traversal with a lane-strided LDS
-// stack (conflict-free: entry e of lane l lives at word e*64+l), 64-byte fp32-outward-rounded node
-// records (two per 128-byte L2 line), 128-byte fp64 triangle records, fp64 shading.
+// stack (conflict-free: entry e of lane l lives at word e*64+l), 32-byte node records with both children's
+// boxes on a 16-bit grid (or 64-byte 4-wide nodes, PRT_BVH_WIDTH), 128-byte fp64 triangle records, fp64 shading.
 //
 // Reference behaviour followed by each function is cited as file:line of Zoz4/Pooraytracer.
 #pragma once
@@ -89,12 +89,13 @@ struct HitInfo {
 
 struct WorkCount {
     uint32_t nodes, tris;
+    uint32_t tris_full; // COUNT builds: triangle tests that went past the plane / interval check (second 64 bytes fetched)
     uint32_t inner_rounds, leaf_rounds; // COUNT builds: wave-level executions of inner_step / leaf_step (lane 0 counts)
 };
 
 // Triangle::Hit + IsInterior (Triangle.cpp:54-83,100-113): same expressions, inclusive interval.
 PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, double tmin, double tmax, double& t_out, double& a_out,
-                      double& b_out, const double4* pre = nullptr) {
+                      double& b_out, const double4* pre = nullptr, uint32_t* n_full = nullptr) {
     const double4* q = reinterpret_cast<const double4*>(T);
     double4 q0 = pre ? *pre : q[0], q1 = q[1]; // `pre`: the record's first 32 bytes, fetched by the caller ahead of time
     d3 n = mk3(q0.x, q0.y, q0.z);
@@ -102,6 +103,7 @@ PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, double tmin, doubl
     if (fabs(denom) < 1e-8) return false;
     double t = (q0.w - dot(n, o)) / denom;
     if (!(tmin <= t && t <= tmax)) return false;
+    if (n_full) ++*n_full;
     // record = n[3] D | w[3] v0.x | v0.yz e0.xy | e0.z e1[3]
     double4 q2 = q[2], q3 = q[3];
     d3 w = mk3(q1.x, q1.y, q1.z);
@@ -159,8 +161,9 @@ PRT_DEV SlabAxis slab_axis(double o, double d, float B, float g0, float gs) {
 // the stepping loop as soon as enough of its lanes have finished (ballot/popcount), hand those lanes
 // their next ray, and come back — lanes never idle for the slowest ray of the wave.
 //
-// The result is tree-independent (closest accepted triangle; on exactly equal t the later-tested one
-// wins, as in the reference).  Box tests are fp32 and strictly conservative (they can only fail to
+// The result does not depend on the tree except for exact ties: the closest accepted triangle is returned, and of
+// two triangles hit at bit-identical t the later-TESTED one wins (inclusive interval, as in the reference) — which
+// one is tested later depends on this tree's visit order, not on the reference's ("Exact ties").  Box tests are fp32 and strictly conservative (they can only fail to
 // cull); every accept/reject of a hit is the fp64 triangle test.  `early`: traversal stops as soon as
 // a hit with t < early is accepted (shadow rays: anything that close is an occluder for certain);
 // -inf for closest-hit.  The stack lives in LDS, lane-strided (`stk` = this lane's column, stride 64).
@@ -201,7 +204,82 @@ struct Trav {
         active = S.n_tris != 0;
     }
 
-    // One inner-node visit: fetch the 64-byte node, test both child boxes, descend / push / pop.
+#if PRT_BVH_WIDTH == 4
+    // Entry / exit parameters of one child box: its three packed (lo | hi << 16) grid ranges against the ray's slabs.
+    PRT_DEV void box4(uint32_t x, uint32_t y, uint32_t z, float& n, float& f) const {
+        float l = fmaf((float)(x & 0xffffu), ax.idq, ax.c_lo), h = fmaf((float)(x >> 16), ax.idq, ax.c_hi);
+        n = fminf(l, h);
+        f = fmaxf(l, h);
+        l = fmaf((float)(y & 0xffffu), ay.idq, ay.c_lo);
+        h = fmaf((float)(y >> 16), ay.idq, ay.c_hi);
+        n = fmaxf(n, fminf(l, h));
+        f = fminf(f, fmaxf(l, h));
+        l = fmaf((float)(z & 0xffffu), az.idq, az.c_lo);
+        h = fmaf((float)(z >> 16), az.idq, az.c_hi);
+        n = fmaxf(fmaxf(n, fminf(l, h)), tminf);
+        f = fminf(fminf(f, fmaxf(l, h)), tbestf);
+    }
+    // One visit of a 4-wide node: four 16-byte loads (x ranges, y ranges, z ranges, refs), four box tests, the
+    // children that are hit sorted by entry distance (5 compare-exchanges on (distance bits, ref) pairs; a miss
+    // or an unused slot sorts last), nearest one next, the others pushed far to near.  The builders guarantee that
+    // the stack cannot overflow (bvh_build.cpp).
+    template <bool COUNT>
+    PRT_DEV void inner_step(const DScene& S, uint32_t* stk, WorkCount& wc) {
+        const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
+        const uint4 bx = np[0], by = np[1], bz = np[2], rf = np[3];
+        if (COUNT) wc.nodes++;
+        float n0, f0, n1, f1, n2, f2, n3, f3;
+        box4(bx.x, by.x, bz.x, n0, f0);
+        box4(bx.y, by.y, bz.y, n1, f1);
+        box4(bx.z, by.z, bz.z, n2, f2);
+        box4(bx.w, by.w, bz.w, n3, f3);
+        // entry distances are >= tminf; as unsigned integers positive floats order like the floats themselves
+        // (a non-positive tmin only costs ordering quality, never correctness)
+        uint32_t k0 = (n0 <= f0 && rf.x != 0x80000000u) ? __float_as_uint(n0) : 0xffffffffu;
+        uint32_t k1 = (n1 <= f1 && rf.y != 0x80000000u) ? __float_as_uint(n1) : 0xffffffffu;
+        uint32_t k2 = (n2 <= f2 && rf.z != 0x80000000u) ? __float_as_uint(n2) : 0xffffffffu;
+        uint32_t k3 = (n3 <= f3 && rf.w != 0x80000000u) ? __float_as_uint(n3) : 0xffffffffu;
+        uint32_t r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
+#define PRT_CE(ka, ra, kb, rb)                  \
+    {                                           \
+        const bool sw_ = kb < ka;               \
+        const uint32_t tk_ = sw_ ? kb : ka;     \
+        kb = sw_ ? ka : kb;                     \
+        ka = tk_;                               \
+        const uint32_t tr_ = sw_ ? rb : ra;     \
+        rb = sw_ ? ra : rb;                     \
+        ra = tr_;                               \
+    }
+        PRT_CE(k0, r0, k1, r1)
+        PRT_CE(k2, r2, k3, r3)
+        PRT_CE(k0, r0, k2, r2)
+        PRT_CE(k1, r1, k3, r3)
+        PRT_CE(k1, r1, k2, r2)
+#undef PRT_CE
+        if (k3 != 0xffffffffu) {
+            stk[sp * 64] = r3;
+            sp++;
+        }
+        if (k2 != 0xffffffffu) {
+            stk[sp * 64] = r2;
+            sp++;
+        }
+        if (k1 != 0xffffffffu) {
+            stk[sp * 64] = r1;
+            sp++;
+        }
+        if (k0 != 0xffffffffu) {
+            cur = (int32_t)r0;
+        } else if (sp == 0) {
+            cur = PRT_NOCUR;
+        } else {
+            sp--;
+            cur = (int32_t)stk[sp * 64];
+        }
+        if (cur == PRT_NOCUR && pend == 0) active = false;
+    }
+#else
+    // One inner-node visit: fetch the 32-byte node, test both child boxes, descend / push / pop.
     template <bool COUNT>
     PRT_DEV void inner_step(const DScene& S, uint32_t* stk, WorkCount& wc) {
 #if PRT_NODE16
@@ -279,6 +357,7 @@ struct Trav {
 #endif
         if (cur == PRT_NOCUR && pend == 0) active = false;
     }
+#endif // PRT_BVH_WIDTH
 
     // fp64 tests of one leaf's triangles (128-byte records); returns true when an early-out hit was accepted.
     template <bool COUNT>
@@ -299,9 +378,9 @@ struct Trav {
 #if PRT_LEAF_PREFETCH
             const double4 q0c = q0n;
             if (i + 1 < cnt) q0n = *reinterpret_cast<const double4*>(S.tris + first + i + 1);
-            if (tri_test(S.tris + first + i, o, d, tmin, hit.t, t, al, be, &q0c)) {
+            if (tri_test(S.tris + first + i, o, d, tmin, hit.t, t, al, be, &q0c, COUNT ? &wc.tris_full : nullptr)) {
 #else
-            if (tri_test(S.tris + first + i, o, d, tmin, hit.t, t, al, be)) {
+            if (tri_test(S.tris + first + i, o, d, tmin, hit.t, t, al, be, nullptr, COUNT ? &wc.tris_full : nullptr)) {
 #endif
                 hit.t = t;
                 hit.alpha = al;

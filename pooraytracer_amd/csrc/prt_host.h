@@ -63,6 +63,8 @@ void setup_materials(const PrtSceneDesc& d, std::vector<DMaterial>& out);
 // Binned-SAH BVH2, depth-bounded to PRT_STACK_DEPTH, child boxes rounded outward to fp32.
 // Returns false (with *err set) if a compiled-in limit is exceeded.
 bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err);
+// Structural check of a flattened tree (refs in range, every triangle in exactly one leaf, stack bound).
+bool validate_nodes(const DNode* nodes, size_t n_nodes, size_t n_tris, std::string* err);
 // Same tree family built on the current HIP device from the same fp32 boxes (n >= 2): Morton sort, box
 // segment tree, level-synchronous SAH splits along the Morton order.  Returns false with *err set.
 bool build_bvh_device(const PrimBox* h_boxes, size_t n, DeviceBVH& out, std::string* err);

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stk = &s_stack[wave][0][lane];
-    WorkCount wc{0, 0, 0, 0};
+    WorkCount wc{0, 0, 0, 0, 0};
     uint32_t nrays = 0;
     Trav tr;
     tr.init(S, mk3(0, 0, 0), mk3(0, 0, 1), 0.0, 0.0, 0.0);
@@ -164,11 +164,13 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
     unsigned long long a = wave_sum((unsigned long long)nrays);
     unsigned long long b = wave_sum((unsigned long long)wc.nodes);
     unsigned long long c = wave_sum((unsigned long long)wc.tris);
+    unsigned long long f = wave_sum((unsigned long long)wc.tris_full);
     if (lane == 0) {
         atomicAdd(&ctr->rays_closest, a);
         if (COUNT) {
             atomicAdd(&ctr->node_fetches, b);
             atomicAdd(&ctr->tri_tests, c);
+            atomicAdd(&ctr->tri_full, f);
         }
     }
 }
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
 // added on the spot, so no per-sample radiance has to live in registers across traversals.
 #define ADD_RADIANCE(x) PST_ST(S_ACC, PST_LD(S_ACC) + (PST_LD(S_BETA) * (x)) * inv_spp)
 
-    WorkCount wc{0, 0, 0, 0};
+    WorkCount wc{0, 0, 0, 0, 0};
     uint32_t n_closest = 0, n_shadow = 0, n_samples = 0, n_refills = 0;
 #if PRT_K3_TIMING
     // developer diagnostic (COUNT instantiation only): 100 MHz timestamps of this wave's start, of the first
@@ -514,12 +516,14 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     unsigned long long c = wave_sum((unsigned long long)n_samples);
     unsigned long long d = wave_sum((unsigned long long)wc.nodes);
     unsigned long long e = wave_sum((unsigned long long)wc.tris);
+    unsigned long long f = wave_sum((unsigned long long)wc.tris_full);
     if (lane == 0) {
         atomicAdd(&ctr->rays_closest, a);
         atomicAdd(&ctr->rays_shadow, b);
         atomicAdd(&ctr->samples, c);
         if (COUNT) {
             atomicAdd(&ctr->node_fetches, d);
+            atomicAdd(&ctr->tri_full, f);
 #if PRT_K3_TIMING
             const unsigned long long tm_end = wall_clock64();
             atomicMax(&ctr->inner_rounds, ~tm_start);               // -> earliest wave start

@@ -1,8 +1,9 @@
 // prt_types.h — device-resident data layouts shared by the host builder and the HIP kernels.
 //
 // HBM layout (all arrays are plain hipMalloc allocations, 128-byte aligned):
-//   DNode   [n_nodes]   64 B  BVH2 inner node: both children's boxes as fp32 rounded OUTWARD
-//                             (conservative cull only; every accept/reject of a hit is fp64) + 2 refs
+//   DNode   [n_nodes]   32 B  BVH2 inner node (PRT_BVH_WIDTH 2): both children's boxes on a 16-bit grid over the scene
+//                             bounds, rounded OUTWARD (conservative cull only; every accept/reject of a hit is
+//                             fp64) + 2 refs; 64 B for the 4-wide node (PRT_BVH_WIDTH 4): four boxes + 4 refs
 //   DTri    [n_tris]   128 B  fp64 intersection record in BVH leaf order (Triangle.cpp:54-83 inputs)
 //   DTriShade[n_tris]   96 B  fp64 shading record in the same order (tangent, texcoords, material)
 //   DMaterial[n_mat]          material table (Material.h parameters)
@@ -11,7 +12,13 @@
 #pragma once
 #include <stdint.h>
 
-#define PRT_STACK_DEPTH 32   // LDS traversal stack entries per lane; builder bounds tree depth to it
+#ifndef PRT_BVH_WIDTH
+#define PRT_BVH_WIDTH 2      // children per node: 2 (32-byte nodes) or 4 (64-byte nodes, collapsed from the same binary tree)
+#endif
+#ifndef PRT_STACK_DEPTH
+#define PRT_STACK_DEPTH 32   // LDS traversal stack entries per lane; the builders bound the stack a traversal can need to it
+#endif
+#define PRT_BVH2_LEVELS 30   // inner-node levels of the binary tree both builders bound their trees to
 #ifndef PRT_LEAF_MAX
 #define PRT_LEAF_MAX 4       // triangles per BVH leaf (leaf ref stores count-1 in 3 bits)
 #endif
@@ -25,7 +32,16 @@
 #define PRT_NODE16 1 // 1: 32-byte nodes, boxes quantised to a 16-bit scene grid; 0: 64-byte fp32 nodes
 #endif
 
-#if PRT_NODE16
+#if PRT_BVH_WIDTH == 4
+// 64 bytes = four 16-byte loads per node visit: the x ranges of the four children, their y ranges, their z ranges,
+// the four refs.  A range is lo | hi << 16 on the same 65536^3 grid as the 2-wide node.  Unused slots hold an
+// inverted range (lo = 0xffff, hi = 0) on every axis, which no ray can hit, and ref = 0x80000000.
+struct alignas(64) DNode {
+    uint32_t bx[4], by[4], bz[4];
+    int32_t ref[4]; // >=0: inner node index; <0: leaf, ~ref = (first_tri << 3) | (count-1)
+};
+static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
+#elif PRT_NODE16
 // 32 bytes = two 16-byte loads per node visit (the texture addresser is the limiter, so bytes and
 // load instructions per visit are what count).  Child boxes are quantised OUTWARD onto a 65536^3
 // grid over the scene bounds: coordinate = grid_origin + q * grid_step.
@@ -141,4 +157,5 @@ struct DCounters {
     unsigned long long next_item;
     unsigned long long rays_closest, rays_shadow, node_fetches, tri_tests, samples;
     unsigned long long inner_rounds, leaf_rounds, refills; // COUNT builds: wave-level scheduling statistics
+    unsigned long long tri_full; // COUNT builds: triangle tests that fetched the whole 128-byte record
 };

@@ -2,6 +2,7 @@
 // Triangle precompute, binned-SAH BVH with 16-bit quantised boxes, light tree — on random and degenerate
 // input, with the tree invariants checked: every triangle in exactly one leaf, every leaf's triangles inside
 // its (dequantised) box, child boxes inside the parent's, depth within the traversal stack.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -52,15 +53,55 @@ static int check_tree(const BuiltBVH& b, const std::vector<HostTri>& tris) {
         }
         if ((size_t)it.ref >= b.nodes.size()) return fail("node index");
         const DNode& nd = b.nodes[it.ref];
+#if PRT_BVH_WIDTH == 4
+        int kids = 0;
+        for (int i = 0; i < 4; ++i) {
+            if (nd.ref[i] == (int32_t)0x80000000) {
+                if (nd.bx[i] != 0x0000ffffu || nd.by[i] != 0x0000ffffu || nd.bz[i] != 0x0000ffffu) return fail("unused slot is not inverted");
+                continue;
+            }
+            ++kids;
+            Box c;
+            const uint32_t w[3] = {nd.bx[i], nd.by[i], nd.bz[i]};
+            for (int a = 0; a < 3; ++a) {
+                const uint16_t q[2] = {(uint16_t)(w[a] & 0xffffu), (uint16_t)(w[a] >> 16)};
+                deq(q, a, c.lo[a], c.hi[a]);
+                // a child box may stick out of its parent's by the outward rounding of one grid step, never more
+                if (c.lo[a] < it.box.lo[a] - 1.0001 * b.grid_step[a] || c.hi[a] > it.box.hi[a] + 1.0001 * b.grid_step[a]) return fail("child box outside its parent");
+            }
+            stack.push_back({nd.ref[i], c, it.depth + 1});
+        }
+        if (kids < 2 && n > 1) return fail("wide node with fewer than two children");
+        continue;
+#else
         Box c0, c1;
         deq(nd.c0x, 0, c0.lo[0], c0.hi[0]); deq(nd.c0y, 1, c0.lo[1], c0.hi[1]); deq(nd.c0z, 2, c0.lo[2], c0.hi[2]);
         deq(nd.c1x, 0, c1.lo[0], c1.hi[0]); deq(nd.c1y, 1, c1.lo[1], c1.hi[1]); deq(nd.c1z, 2, c1.lo[2], c1.hi[2]);
         stack.push_back({nd.ref0, c0, it.depth + 1});
         if (!(n == 1 && nd.ref1 == nd.ref0)) stack.push_back({nd.ref1, c1, it.depth + 1});
+#endif
     }
     for (size_t i = 0; i < n; ++i)
         if (seen[i] != 1) return fail("triangle not in exactly one leaf");
+#if PRT_BVH_WIDTH == 4
+    // worst-case stack use of a traversal: entering a node with k children leaves up to k-1 siblings on the stack
+    std::vector<int> need(b.nodes.size(), 0);
+    for (size_t i = b.nodes.size(); i-- > 0;) { // children have larger indices than their parent
+        int k = 0, worst = 0;
+        for (int c = 0; c < 4; ++c) {
+            if (b.nodes[i].ref[c] == (int32_t)0x80000000) continue;
+            ++k;
+            if (b.nodes[i].ref[c] >= 0) {
+                if ((size_t)b.nodes[i].ref[c] <= i) return fail("child index not after its parent");
+                worst = std::max(worst, need[b.nodes[i].ref[c]]);
+            }
+        }
+        need[i] = k - 1 + worst;
+    }
+    if (!need.empty() && need[0] > PRT_STACK_DEPTH) return fail("a traversal could overflow the stack");
+#else
     if (max_depth > PRT_STACK_DEPTH - 1) return fail("tree deeper than the traversal stack");
+#endif
     return 0;
 }
 
@@ -114,6 +155,7 @@ int main() {
         if (!build_bvh(tris, b, &err)) return fail(err.c_str());
         if (b.order.size() != n) return fail("order size");
         if (check_tree(b, tris)) return 1;
+        if (!validate_nodes(b.nodes.data(), b.nodes.size(), n, &err)) return fail(err.c_str());
         std::vector<double> moved(v);
         for (double& x : moved) x = x * 1.5 + 0.25;
         update_triangles(moved.data(), nullptr, tris);
