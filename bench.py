@@ -2,128 +2,180 @@
 """bench.py — headline benchmark of the MI355X path-tracing hot path.
 
 Metric (BASELINE.json): Mrays/s (primary + secondary) and wall-clock s/frame at fixed spp.
-Workload at N=1 (BASELINE.json configs[1]): synthetic "cornell-box" stand-in (scenes.cornell_box,
+Headline workload (BASELINE.json configs[1]): synthetic "cornell-box" stand-in (scenes.cornell_box,
 20,492 triangles — the reference's asset is not available), 1024x1024, spp=500, depth=20, RR 0.8,
 bSampleLights, seed 1, fp64 arithmetic (the reference's).  One "step" = one full frame
 (Camera::Render): K3 persistent path-tracing kernel + K5 finalize, inputs (scene, BVH) resident in HBM.
 
-N>1: one process per GPU (torch.distributed, backend nccl = RCCL).  The SAME frame is cut into 16x16
-tiles dealt diagonally over ranks (strong scaling: total work fixed); every rank renders its tiles
-into a zero-initialised full-size fp32 framebuffer and one RCCL reduce(sum) to rank 0 assembles the
-image (disjoint tiles => x + 0 + ... + 0, bit-identical to the 1-GPU image).  The reduce is inside
-the timed region.  For N>1 consecutive frames alternate between two HIP streams / framebuffers so the
-next frame fills the GPU while the previous one drains and is being reduced (--no-pipeline turns it
-off; at N=1 frames run back to back on one stream unless --pipeline is given).
+`python bench.py --gpus N` is a complete N-rank run: with WORLD_SIZE unset and N > 1 this process starts
+N rank processes (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE it
+touches a GPU, waits for them and exits with their worst return code.  Under torch.distributed.run the
+ranks already exist and the same code runs in each.  Ranks form an `nccl` (= RCCL) group and assert that
+its size is N.
+
+N>1: the SAME frame is cut into 16x16 tiles dealt diagonally over ranks (strong scaling: total work
+fixed); every rank renders its tiles into a zero-initialised full-size fp32 framebuffer and one RCCL
+reduce(sum) to rank 0 assembles the image (disjoint tiles => x + 0 + ... + 0, bit-identical to the 1-GPU
+image).  The reduce is inside the timed region; consecutive frames alternate between two HIP streams /
+framebuffers so the next frame fills the GPU while the previous one drains and is being reduced.  After
+the timed region rank 0 renders the frame alone and compares (`assembled_equals_single_rank`), and
+BASELINE config 5 (bathroom2 spp=500 depth=50) is timed the same way (`config5`).
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline     dominant kernel k_render: algorithmic bytes per launch / mean launch duration measured
-               live with HIP events on the launch stream around every launch of the timed region
-               (overlapped launches, N>1 only: the launch period instead, see kernel_ms_source).
-  cpu_baseline the CPU oracle (port of the reference algorithm, oracle/pt_oracle.cpp) timed on this
-               box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+  roofline      dominant kernel: what bounds it according to the PMC counters of the same build
+                (profiles/pmc_summary.json, separate rocprofv3 --pmc passes), priced with the launch
+                duration measured live with HIP events on the launch stream.
+  cpu_baseline  the CPU oracle (port of the reference algorithm, oracle/pt_oracle.cpp) timed on this
+                box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+  parity_check  the rows the CPU baseline rendered, compared with an fp64 GPU frame of the same
+                configuration (1e-9 per channel); a mismatch makes the bench fail.
+  workloads     (N=1) the other single-GPU workloads, each with its own roofline / parity entry.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E nominal (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E nominal (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+N_SIMD = 256 * 4          # 256 CUs x 4 SIMDs
+PEAK_CLOCK_GHZ = 2.4
+VALU_PEAK_GINST = N_SIMD * PEAK_CLOCK_GHZ / 4.0  # one wave64 VALU instruction per SIMD per 4 cycles = 614.4 G/s
 
 WORKLOADS = {
     # name: (scene factory name, kwargs, spp, depth)
     "cornell-box": ("cornell_box", {}, 500, 20),
     "veach-mis": ("veach_mis", {}, 3000, 100),
     "bathroom2": ("bathroom", {}, 100, 50),
+    "bathroom2-spp500": ("bathroom", {}, 500, 50),            # BASELINE config 5 (the 8-GPU configuration)
+    "cornell-ct": ("cornell_box", {"ball_cooktorrance_alpha": 0.1}, 100, 10),  # Results/..._alpha0.1.png configuration
 }
 # K1 closest-hit microbenchmarks (SURVEY.md §8d S0 / S4): 2^24 seeded incoherent rays resident in HBM
 RAY_WORKLOADS = {
-    "s0-rays-cornell": ("cornell_box", {}),                          # cache-resident geometry
-    "s4-rays-soup8m": ("triangle_soup", {"n_tris": 8_000_000}),      # HBM-resident: 256 MB nodes + 1 GB triangles
+    "s0-rays-cornell": ("cornell_box", {}, False),                          # cache-resident geometry
+    "s4-rays-soup8m": ("triangle_soup", {"n_tris": 8_000_000}, True),       # HBM-resident; tree built on the GPU
 }
+EXTRA_AT_N1 = ["veach-mis", "bathroom2", "cornell-ct", "s0-rays-cornell", "s4-rays-soup8m"]
+TOL = 1e-9  # per channel, relative to max(1, |x|): fp64 on both sides, differences = FMA contraction + libm ulps
 
 
-def run_ray_microbench(args, torch, api, scenes):
-    """One step = one K1 launch over 2^24 rays (rays and hits stay in HBM)."""
-    import numpy as np
-    fn, kw = RAY_WORKLOADS[args.workload]
-    data = getattr(scenes, fn)(**kw)
-    t0 = time.time()
-    sc = api.Scene(data)
-    build_s = time.time() - t0
-    sc.upload(0)
-    n = 1 << 24
-    lo, hi = data.bounds()
-    rays_np = scenes.random_rays(n, lo, hi, seed=12345)
-    d_r = torch.from_numpy(rays_np.view(np.float64).reshape(-1, 8)).cuda()
-    d_h = torch.zeros((n, 4), dtype=torch.float64, device="cuda")
-    for _ in range(args.warmup):
-        sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr())
-    torch.cuda.synchronize()
-    ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr())
-        ms.append(sc.counters()["kernel_ms"])
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr(), count_work=True)
-    torch.cuda.synchronize()
-    cc = sc.counters()
-    npr, tpr = cc["node_fetches"] / n, cc["tri_tests"] / n
-    bpr = bytes_per_ray(npr, tpr)
-    mean_ms = sum(ms) / len(ms)
-    achieved = bpr * n / (mean_ms * 1e-3) / 1e9
-    hits = d_h.cpu().numpy().view(np.dtype([("t", "<f8"), ("a", "<f8"), ("b", "<f8"), ("prim", "<i4"), ("front", "<i4")])).reshape(-1)
-    out = {
-        "metric": "Mrays/s (closest-hit, incoherent rays)", "value": round(n * args.steps / elapsed / 1e6, 2), "unit": "Mrays/s",
-        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {n} seeded random rays vs {data.n_tris} triangles "
-                               f"({cc['bvh_nodes']} BVH nodes, depth {cc['bvh_depth']}, host build {build_s:.1f} s)",
-                   "hit_fraction": round(float((hits["prim"] >= 0).mean()), 4)},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "k_trace_closest",
-                     "kernel_ms": round(mean_ms, 3), "bytes_per_ray": round(bpr, 1), "nodes_per_ray": round(npr, 2),
-                     "tris_per_ray": round(tpr, 2)},
-    }
-    if not args.no_cpu_baseline:
-        import oracle
-        orc = oracle.Oracle(data) if data.n_tris <= 200_000 else None
-        if orc is not None:
-            m = 200_000
-            t0 = time.time()
-            orc.trace_closest(rays_np[:m])
-            dt = time.time() - t0
-            out["cpu_baseline"] = {"value": round(m / dt / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port",
-                                   "sample": f"first {m} rays of the same batch, single thread ({dt:.2f} s)"}
-    print(json.dumps(out), flush=True)
+# ------------------------------------------------------------------------------------------------ launcher
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
+def spawn_ranks(n):
+    """Start n rank processes of this script, one per GPU.  Nothing here initialises a GPU: the children do."""
+    rehearsal = os.environ.get("PRT_BENCH_REHEARSAL") == "1"
+    if not rehearsal and os.environ.get("PRT_BENCH_LAUNCH_STUB") != "1":
+        import torch
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
+        if have < n:
+            raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
+    port = str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    raise SystemExit(rc)
 
-NODE_BYTES = 32.0   # DNode: both children's boxes on a 16-bit grid + 2 refs (csrc/prt_types.h)
-TRI_BYTES = 128.0   # DTri: fp64 n, D, w, v0, e0, e1
+
+# ------------------------------------------------------------------------------------------------ rooflines
+def record_bytes(info):
+    return float(info["node_bytes"])
 
 
-def bytes_per_ray(nodes_per_ray, tris_per_ray):
-    """SURVEY.md §8(d) with this build's record sizes: ray in (64 B fp64 o,tmin,d,tmax) + hit out (32 B)
-    + 32 B per BVH node record fetched + 128 B per fp64 triangle record tested (counters from the
-    counting instantiation of the same kernel)."""
-    return 64.0 + 32.0 + NODE_BYTES * nodes_per_ray + TRI_BYTES * tris_per_ray
+def bytes_per_ray(cc, info):
+    """Algorithmic bytes per ray, SURVEY.md §8(d) with this build's record sizes and what the kernel really fetches
+    (counters of the counting instantiation of the same kernel): ray in (64 B: fp64 o, tmin, d, tmax) + hit out (32 B)
+    + one node record per node visit + 32 B (plane n, D) per triangle test + 96 B (w, v0, e0, e1) per test that
+    passed the plane / interval check and fetched the rest of the 128-byte record."""
+    rays = max(1, cc["rays_closest"] + cc["rays_shadow"])
+    npr, tpr, fpr = cc["node_fetches"] / rays, cc["tri_tests"] / rays, cc["tri_full"] / rays
+    return 64.0 + 32.0 + record_bytes(info) * npr + 32.0 * tpr + 96.0 * fpr, npr, tpr, fpr
+
+
+def load_pmc(workload):
+    p = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        return json.load(open(p)).get(workload.split("-spp")[0])  # bathroom2-spp500 scales from bathroom2's per-ray counters
+    except Exception:
+        return None
+
+
+def roofline(workload, kernel, bpr, npr, tpr, fpr, rays_per_launch, extra_bytes, kernel_ms, kernel_ms_source):
+    """What bounds the dominant kernel.  The PMC counters (profiles/pmc_summary.json: per launch, with the rays of that
+    launch) decide: a launch whose HBM-side traffic is a large share of the peak is HBM-bound and is priced in bytes;
+    a cache-resident one is priced by the issue rate of its vector instructions."""
+    sec = kernel_ms * 1e-3
+    alg_gbps = (bpr * rays_per_launch + extra_bytes) / sec / 1e9
+    pmc = load_pmc(workload)
+    out = {"kernel": kernel, "kernel_ms": round(kernel_ms, 3), "kernel_ms_source": kernel_ms_source,
+           "bytes_per_ray": round(bpr, 1), "nodes_per_ray": round(npr, 2), "tris_per_ray": round(tpr, 2),
+           "tris_full_per_ray": round(fpr, 2), "algorithmic_gbps": round(alg_gbps, 1),
+           "algorithmic_frac_of_hbm_peak": round(alg_gbps / HBM_PEAK_GBPS, 4)}
+    scale = None
+    if pmc and pmc.get("rays_per_launch"):
+        scale = rays_per_launch / float(pmc["rays_per_launch"])  # counters scale with the rays of the launch
+        out["pmc_round"] = pmc.get("round")
+    traffic = pmc["hbm_bytes_per_launch"] * scale if scale and "hbm_bytes_per_launch" in pmc else None
+    hbm_gbps = traffic / sec / 1e9 if traffic else None
+    if hbm_gbps is not None:
+        out["hbm_gbps_measured"] = round(hbm_gbps, 1)
+        out["hbm_frac_measured"] = round(hbm_gbps / HBM_PEAK_GBPS, 4)
+    valu = pmc["counters_per_launch"].get("SQ_INSTS_VALU") * scale if scale and "SQ_INSTS_VALU" in pmc.get("counters_per_launch", {}) else None
+    if pmc:
+        for k in ("valu_busy_frac", "wait_any_frac", "l2_hit_rate", "clock_ghz"):
+            if k in pmc:
+                out["pmc_" + k] = pmc[k]
+    if hbm_gbps is not None and hbm_gbps >= 0.4 * HBM_PEAK_GBPS:
+        out.update(bound="hbm", achieved=round(alg_gbps, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                   frac=round(alg_gbps / HBM_PEAK_GBPS, 4), traffic=traffic)
+    elif valu is not None:
+        ginst = valu / sec / 1e9
+        out.update(bound="valu", achieved=round(ginst, 1), peak=round(VALU_PEAK_GINST, 1), unit="Ginstr/s",
+                   frac=round(ginst / VALU_PEAK_GINST, 4), traffic=traffic,
+                   valu_insts_per_ray=round(valu / rays_per_launch, 2))
+    else:  # no counters for this build yet: the algorithmic figure only, flagged
+        out.update(bound="hbm", achieved=round(alg_gbps, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                   frac=round(alg_gbps / HBM_PEAK_GBPS, 4), traffic=None, note="no PMC summary for this workload")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline + parity
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(scene_data, spp, depth, seed, target_s=8.0):
-    """Time the CPU oracle (kind "port") on a bounded sample: centre rows of the same image at the
-    same spp/depth, all host threads as independent row workers with keyed per-sample RNG."""
-    import oracle  # test infrastructure used here only as the reported CPU baseline
+    """Time the CPU oracle (kind "port") on a bounded sample: centre rows of the same image at the same spp/depth,
+    all host threads as independent row workers with keyed per-sample RNG; plus one row-band single-threaded.
+    Returns (json object, rendered rows image, (y0, y1))."""
+    import oracle  # test infrastructure used here only as the reported CPU baseline and as the parity checker
     threads = max(1, min(len(os.sched_getaffinity(0)), 16))  # the GPU box gives one GPU a 16-core CPU share
     orc = oracle.Oracle(scene_data)
     cam = scene_data.camera
     mid = cam.height // 2
-    # calibration: a few rows at low spp
     t = time.time()
     _, c = orc.render(spp=8, max_depth=depth, seed=seed, rows=(mid, mid + threads), nthreads=threads)
     dt = max(time.time() - t, 1e-3)
@@ -132,10 +184,15 @@ def cpu_baseline(scene_data, spp, depth, seed, target_s=8.0):
     rows = max(threads, (rows // threads) * threads)
     y0 = max(0, mid - rows // 2)
     t = time.time()
-    _, c = orc.render(spp=spp, max_depth=depth, seed=seed, rows=(y0, y0 + rows), nthreads=threads)
+    img, c = orc.render(spp=spp, max_depth=depth, seed=seed, rows=(y0, y0 + rows), nthreads=threads)
     dt = time.time() - t
     rays = c["rays_closest"] + c["rays_shadow"]
-    return {
+    # single thread: a bounded share of one row
+    spp1 = max(1, min(spp, int(paths_per_s / threads * 2.0 / cam.width)))
+    t = time.time()
+    _, c1 = orc.render(spp=spp1, max_depth=depth, seed=seed, rows=(mid, mid + 1), nthreads=1)
+    dt1 = max(time.time() - t, 1e-6)
+    out = {
         "value": round(rays / dt / 1e6, 3),
         "unit": "Mrays/s",
         "cores": threads,
@@ -144,76 +201,51 @@ def cpu_baseline(scene_data, spp, depth, seed, target_s=8.0):
                   f"({c['samples']} camera samples, {rays} rays, {dt:.2f} s, {threads} row-worker threads)",
         "mpaths_per_s": round(c["samples"] / dt / 1e6, 4),
         "seconds": round(dt, 2),
+        "cpu_model": cpu_model(),
+        "single_thread": {"value": round((c1["rays_closest"] + c1["rays_shadow"]) / dt1 / 1e6, 3), "unit": "Mrays/s",
+                          "mpaths_per_s": round(c1["samples"] / dt1 / 1e6, 4),
+                          "sample": f"row {mid} at spp={spp1} ({dt1:.2f} s)"},
+        "ray_count_note": "the oracle counts every world.Hit the reference issues; the GPU does not trace rays whose "
+                          "result the reference discards, so compare paths/s (gpu_over_cpu_paths), not rays/s",
     }
+    return out, img, (y0, y0 + rows)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell-box", choices=sorted(WORKLOADS) + sorted(RAY_WORKLOADS))
-    ap.add_argument("--spp", type=int, default=0, help="override spp (0 = the workload's)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true", help="one stream, one framebuffer: frames strictly back to back")
-    ap.add_argument("--pipeline", action="store_true", help="alternate two streams / framebuffers also at N=1 (default: only for N>1)")
-    args = ap.parse_args()
+def parity_rows(gpu_f64, ref_img, rows):
+    import numpy as np
+    y0, y1 = rows
+    g, r = gpu_f64[y0:y1], ref_img[y0:y1]
+    scale = np.maximum(1.0, np.abs(r))
+    rel = np.abs(g - r) / scale
+    bad = (rel > TOL).any(-1)
+    return {"rows": [int(y0), int(y1)], "pixels": int(bad.size), "bad_px": int(bad.sum()),
+            "max_rel": float(rel.max()) if rel.size else 0.0, "tolerance": TOL,
+            "ok": bool(bad.mean() <= 1e-3 if bad.size else True)}
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world != 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    nranks = world
 
-    import torch
-    import torch.distributed as dist
-    from pooraytracer_amd import api, build, distributed, scenes
+# ------------------------------------------------------------------------------------------------ workloads
+class Ctx:
+    pass
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    if rank == 0:
-        build.build()  # no-op when libprt_hip.so is fresh
-    # PRT_BENCH_REHEARSAL=1: exercise the N>1 path on a ONE-GPU box — every rank shares cuda:0 and the
-    # reduce goes through gloo on host copies (RCCL refuses two ranks on one device).  Not a measurement.
-    rehearsal = os.environ.get("PRT_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    force_dist = os.environ.get("PRT_BENCH_FORCE_DIST") == "1"  # test hook: RCCL process group even at N=1
-    if nranks > 1 or force_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        if rehearsal:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=nranks)
-        else:
-            dist.init_process_group(backend="nccl", rank=rank, world_size=nranks,
-                                    device_id=torch.device("cuda", local_rank))
-        dist.barrier()
 
-    if args.workload in RAY_WORKLOADS:
-        if nranks != 1:
-            raise SystemExit("ray microbenchmarks are single-GPU")
-        run_ray_microbench(args, torch, api, scenes)
-        return
-    fn, kw, spp, depth = WORKLOADS[args.workload]
-    if args.spp > 0:
-        spp = args.spp
+def time_render(ctx, name, steps, warmup, spp_override=0, with_cpu=True, cpu_target_s=8.0):
+    """Times `steps` frames of a render workload on the current rank set; returns the JSON object of the workload."""
+    torch, dist, api, scenes, distributed = ctx.torch, ctx.dist, ctx.api, ctx.scenes, ctx.distributed
+    rank, nranks, rehearsal = ctx.rank, ctx.nranks, ctx.rehearsal
+    fn, kw, spp, depth = WORKLOADS[name]
+    if spp_override > 0:
+        spp = spp_override
     seed = 1
     data = getattr(scenes, fn)(**kw)
     cam = data.camera
-    sc = api.Scene(data).upload(local_rank)
-    # Two framebuffers on two HIP streams: consecutive frames alternate, so frame k+1 starts filling the
-    # GPU while the last long paths of frame k drain and its framebuffer is being reduced (RCCL overlaps
-    # with compute).  Every step is still one complete frame; libprt_hip double-buffers its per-call state.
-    # Pipelining is for N > 1 (a 1/N tile share makes the fixed fill+drain of a launch matter; at N = 1 it is
-    # worth 2 %).  At N = 1 the frames run back to back on one stream so that the HIP events around each launch
-    # bracket exactly that launch: overlapped launches would each be timed from submission, i.e. including the
-    # wait for the previous frame's wave slots (measured: 834 ms per launch for a 418 ms launch period), and the
-    # roofline below would be computed from a duration that is not the kernel's.  --pipeline forces it on.
-    pipelined = (args.pipeline or nranks > 1) and not args.no_pipeline and not rehearsal
+    sc = api.Scene(data).upload(ctx.local_rank)
+    info = sc.bvh_info()
+    # Two framebuffers on two HIP streams: consecutive frames alternate, so frame k+1 starts filling the GPU while
+    # the last long paths of frame k drain and its framebuffer is being reduced (RCCL overlaps with compute).  Every
+    # step is still one complete frame; libprt_hip double-buffers its per-call state.  At N = 1 the frames run back
+    # to back on one stream so that the HIP events around each launch bracket exactly that launch.
+    pipelined = (ctx.args.pipeline or nranks > 1) and not ctx.args.no_pipeline and not rehearsal
     fbs = [torch.zeros((cam.height, cam.width, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
-    fb = fbs[0]
     streams = [torch.cuda.Stream(), torch.cuda.Stream()] if pipelined else [torch.cuda.current_stream()] * 2
     stream = torch.cuda.current_stream().cuda_stream
     render_kw = dict(spp=spp, max_depth=depth, seed=seed, rank=rank, nranks=nranks, tile_size=16 if nranks > 1 else 32)
@@ -234,25 +266,25 @@ def main():
                 distributed.reduce_framebuffer(buf, dst=0)
 
     def fence():
-        if nranks > 1 or force_dist:
+        if ctx.in_group:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
+    for k in range(warmup):
         step(k)
     fence()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         step(k, evs[k])
     fence()
     elapsed = time.perf_counter() - t0
     # HIP events recorded on the stream each K3 was launched on (memsets + K3 + K5; K3 is > 99.9 % of it)
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
     c = sc.counters()  # ray counters of the last frame; every frame traces exactly the same rays (keyed RNG)
-    rays = (c["rays_closest"] + c["rays_shadow"]) * args.steps
-    samples = c["samples"] * args.steps
-    fb = fbs[(args.steps - 1) % 2]
+    rays = (c["rays_closest"] + c["rays_shadow"]) * steps
+    samples = c["samples"] * steps
+    fb = fbs[(steps - 1) % 2]
 
     if nranks > 1:
         t = torch.tensor([elapsed, float(rays), float(samples)], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
@@ -262,82 +294,238 @@ def main():
         elapsed = float(tmax[0])
         rays, samples = int(t[1]), int(t[2])
 
-    if rank == 0 and nranks > 1 and os.environ.get("PRT_BENCH_VERIFY") == "1":
-        # outside the timed region: the reduced framebuffer must equal a single-rank render bit for bit
-        assembled = fb.clone()
-        sc.render_device(None, fb.data_ptr(), stream=stream, **dict(render_kw, rank=0, nranks=1))
-        torch.cuda.synchronize()
-        print("[bench] N=%d assembled image %s the single-rank image" %
-              (nranks, "EQUALS" if torch.equal(assembled, fb) else "DIFFERS FROM"), file=sys.stderr, flush=True)
+    out = None
     if rank == 0:
-        # counting instantiation (outside the timed region): mean node fetches / triangle tests per ray
+        out = {"workload": name, "value": round(rays / elapsed / 1e6, 2), "unit": "Mrays/s", "steps": steps, "warmup": warmup,
+               "ms_per_step": round(elapsed / steps * 1e3, 3), "mpaths_per_s": round(samples / elapsed / 1e6, 3),
+               "rays_per_frame": int(rays / steps),
+               "config": f"{name} (synthetic stand-in, {data.n_tris} tris, {info['width']}-wide BVH {info['n_nodes']} nodes) "
+                         f"{cam.width}x{cam.height} spp={spp} depth={depth} rr=0.8 bSampleLights seed={seed}",
+               "tile_size": render_kw["tile_size"], "pipelined": bool(pipelined)}
+        if nranks > 1:
+            # outside the timed region: the reduced framebuffer must equal a single-rank render bit for bit
+            assembled = fb.clone()
+            sc.render_device(None, fb.data_ptr(), stream=stream, **dict(render_kw, rank=0, nranks=1))
+            torch.cuda.synchronize()
+            out["assembled_equals_single_rank"] = bool(torch.equal(assembled, fb))
+        # counting instantiation (outside the timed region): node fetches / triangle tests per ray
         torch.cuda.synchronize()
-        sc.render_device(None, fb.data_ptr(), count_work=True, stream=stream,
-                         **dict(render_kw, spp=min(spp, 8), rank=0, nranks=1))
+        sc.render_device(None, fb.data_ptr(), count_work=True, stream=stream, **dict(render_kw, spp=min(spp, 8), rank=0, nranks=1))
         torch.cuda.synchronize()
-        cc = sc.counters()
-        cr = max(1, cc["rays_closest"] + cc["rays_shadow"])
-        npr, tpr = cc["node_fetches"] / cr, cc["tri_tests"] / cr
-        bpr = bytes_per_ray(npr, tpr)
-        rays_per_launch = rays / args.steps / nranks  # this rank's launch (tiles are balanced round-robin)
+        bpr, npr, tpr, fpr = bytes_per_ray(sc.counters(), info)
+        rays_per_launch = rays / steps / nranks  # this rank's launch (tiles are balanced round-robin)
         mean_ms = sum(kernel_ms) / len(kernel_ms)
+        src = "HIP events around each launch"
         if pipelined:
-            # overlapped launches: an event pair spans the queueing behind the previous frame as well, so the
-            # launch PERIOD (timed region / launches) is the per-launch duration the roofline is priced with
-            mean_ms = elapsed * 1e3 / args.steps
+            # overlapped launches: an event pair spans the queueing behind the previous frame as well, so the launch
+            # PERIOD (timed region / launches) is the per-launch duration the roofline is priced with
+            mean_ms, src = elapsed * 1e3 / steps, "launch period of overlapped launches"
         fb_bytes = 24.0 * cam.width * cam.height / nranks  # fp64 per-item partial sums written by K3
-        achieved = (bpr * rays_per_launch + fb_bytes) / (mean_ms * 1e-3) / 1e9
-        out = {
-            "metric": "Mrays/s (primary+secondary) at fixed spp; s/frame in ms_per_step",
-            "value": round(rays / elapsed / 1e6, 2),
-            "unit": "Mrays/s",
-            "n_gpus": nranks,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
-            "config": {
-                "workload": f"{args.workload} (synthetic stand-in, {data.n_tris} tris) {cam.width}x{cam.height} "
-                            f"spp={spp} depth={depth} rr=0.8 bSampleLights seed={seed}",
-                "parallelism": f"{render_kw['tile_size']}x{render_kw['tile_size']} tiles dealt diagonally over {nranks} GPU(s)" + ("; frames pipelined on 2 streams" if pipelined else "") + (" + RCCL reduce(sum) of fp32 framebuffer" if nranks > 1 else ""),
-                "mpaths_per_s": round(samples / elapsed / 1e6, 3),
-                "rays_per_frame": int(rays / args.steps),
-                "s_per_frame": round(elapsed / args.steps, 4),
-            },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": None,
-                "kernel": "k_render",
-                "kernel_ms": round(mean_ms, 3),
-                "kernel_ms_source": "launch period of overlapped launches" if pipelined else "HIP events around each launch",
-                "bytes_per_ray": round(bpr, 1),
-                "nodes_per_ray": round(npr, 2),
-                "tris_per_ray": round(tpr, 2),
-            },
-        }
-        prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(prof):  # PMC-measured HBM bytes per launch of this workload (separate rocprofv3 --pmc passes)
-            try:
-                tr = json.load(open(prof)).get(args.workload)
-                if tr and tr.get("spp") == spp and nranks == 1:
-                    out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-            except Exception:
-                pass
-        if nranks == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(data, spp, depth, seed)
-            out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / max(out["cpu_baseline"]["value"], 1e-9), 1)
+        out["roofline"] = roofline(name, "k_render", bpr, npr, tpr, fpr, rays_per_launch, fb_bytes, mean_ms, src)
+        if nranks == 1 and with_cpu and not ctx.args.no_cpu_baseline:
+            base, ref_img, rows = cpu_baseline(data, spp, depth, seed, target_s=cpu_target_s)
+            base["gpu_over_cpu"] = round(out["value"] / max(base["value"], 1e-9), 1)
+            base["gpu_over_cpu_paths"] = round(out["mpaths_per_s"] / max(base["mpaths_per_s"], 1e-9), 1)
+            out["cpu_baseline"] = base
+            # parity on exactly this configuration: one fp64 frame of the same (spp, depth, seed), outside the timed region
+            f64 = torch.zeros((cam.height, cam.width, 3), dtype=torch.float64, device="cuda")
+            sc.render_device(f64.data_ptr(), None, stream=stream, **dict(render_kw, rank=0, nranks=1))
+            torch.cuda.synchronize()
+            out["parity_check"] = parity_rows(f64.cpu().numpy(), ref_img, rows)
+    sc.close()
+    return out
+
+
+def time_rays(ctx, name, steps, warmup):
+    """One step = one K1 launch over 2^24 rays (rays and hits stay in HBM)."""
+    import numpy as np
+    torch, api, scenes = ctx.torch, ctx.api, ctx.scenes
+    fn, kw, device_bvh = RAY_WORKLOADS[name]
+    data = getattr(scenes, fn)(**kw)
+    t0 = time.time()
+    sc = api.Scene(data, device_bvh=device_bvh)
+    sc.upload(0)
+    build_s = time.time() - t0
+    info = sc.bvh_info()
+    n = 1 << 24
+    lo, hi = data.bounds()
+    rays_np = scenes.random_rays(n, lo, hi, seed=12345)
+    d_r = torch.from_numpy(rays_np.view(np.float64).reshape(-1, 8)).cuda()
+    d_h = torch.zeros((n, 4), dtype=torch.float64, device="cuda")
+    for _ in range(warmup):
+        sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr())
+    torch.cuda.synchronize()
+    ms = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr())
+        ms.append(sc.counters()["kernel_ms"])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr(), count_work=True)
+    torch.cuda.synchronize()
+    cc = sc.counters()
+    cc["rays_closest"], cc["rays_shadow"] = n, 0
+    bpr, npr, tpr, fpr = bytes_per_ray(cc, info)
+    hits = d_h.cpu().numpy().view(np.dtype([("t", "<f8"), ("a", "<f8"), ("b", "<f8"), ("prim", "<i4"), ("front", "<i4")])).reshape(-1)
+    out = {"workload": name, "value": round(n * steps / elapsed / 1e6, 2), "unit": "Mrays/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed / steps * 1e3, 3), "rays_per_launch": n,
+           "config": f"{name}: {n} seeded random rays vs {data.n_tris} triangles ({info['width']}-wide BVH, {info['n_nodes']} nodes, "
+                     f"depth {info['depth']}, {'GPU' if info['built_on_device'] else 'host'} build, create+upload {build_s:.1f} s)",
+           "hit_fraction": round(float((hits["prim"] >= 0).mean()), 4),
+           "roofline": roofline(name, "k_trace_closest", bpr, npr, tpr, fpr, n, 0.0, sum(ms) / len(ms), "HIP events around each launch")}
+    if not ctx.args.no_cpu_baseline and data.n_tris <= 200_000:
+        import oracle
+        orc = oracle.Oracle(data)
+        m = 200_000
+        t0 = time.time()
+        ref = orc.trace_closest(rays_np[:m])
+        dt = time.time() - t0
+        out["cpu_baseline"] = {"value": round(m / dt / 1e6, 3), "unit": "Mrays/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+                               "sample": f"first {m} rays of the same batch, single thread ({dt:.2f} s)"}
+        g = hits[:m]
+        same = (g["prim"] == ref["prim"]) | (g["t"] == ref["t"])  # exact ties may name the other triangle
+        hit = ref["prim"] >= 0
+        terr = np.abs(g["t"][hit] - ref["t"][hit]) / np.maximum(1.0, ref["t"][hit])
+        out["parity_check"] = {"rays": m, "prim_mismatch": int((~same).sum()), "max_rel_t": float(terr.max()) if terr.size else 0.0,
+                               "tolerance": 1e-12, "ok": bool((~same).sum() == 0 and (terr.size == 0 or terr.max() <= 1e-12))}
+    sc.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cornell-box", choices=sorted(WORKLOADS) + sorted(RAY_WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override spp (0 = the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="headline workload only (no `workloads` / `config5` entries)")
+    ap.add_argument("--no-pipeline", action="store_true", help="one stream, one framebuffer: frames strictly back to back")
+    ap.add_argument("--pipeline", action="store_true", help="alternate two streams / framebuffers also at N=1 (default: only for N>1)")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)  # does not return
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    nranks = world
+    if os.environ.get("PRT_BENCH_LAUNCH_STUB") == "1":
+        # launcher test hook (no GPU, no torch): every rank reports what it was given; rank 0 prints the JSON line
+        print(json.dumps({"stub": True, "rank": rank, "n_gpus": nranks, "master": os.environ.get("MASTER_ADDR"),
+                          "port": os.environ.get("MASTER_PORT")}), flush=True)
+        return
+
+    import torch
+    import torch.distributed as dist
+    from pooraytracer_amd import api, build, distributed, scenes
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if rank == 0:
+        build.build()  # no-op when libprt_hip.so is fresh
+    # PRT_BENCH_REHEARSAL=1: exercise the N>1 path on a ONE-GPU box — every rank shares cuda:0 and the
+    # reduce goes through gloo on host copies (RCCL refuses two ranks on one device).  Not a measurement.
+    rehearsal = os.environ.get("PRT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    force_dist = os.environ.get("PRT_BENCH_FORCE_DIST") == "1"  # test hook: RCCL process group even at N=1
+    in_group = nranks > 1 or force_dist
+    if in_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if rehearsal:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=nranks)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=nranks, device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+        assert rehearsal or dist.get_backend() == "nccl"
+        dist.barrier()
+
+    ctx = Ctx()
+    ctx.args, ctx.torch, ctx.dist, ctx.api, ctx.scenes, ctx.distributed = args, torch, dist, api, scenes, distributed
+    ctx.rank, ctx.local_rank, ctx.nranks, ctx.rehearsal, ctx.in_group = rank, local_rank, nranks, rehearsal, in_group
+
+    ok = True
+    if args.workload in RAY_WORKLOADS:
+        if nranks != 1:
+            raise SystemExit("ray microbenchmarks are single-GPU")
+        w = time_rays(ctx, args.workload, args.steps, args.warmup)
+        out = {"metric": "Mrays/s (closest-hit, incoherent rays)", "value": w["value"], "unit": "Mrays/s", "n_gpus": 1,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": w["ms_per_step"], "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": w["config"], "hit_fraction": w["hit_fraction"], "rays_per_launch": w["rays_per_launch"]},
+               "roofline": w["roofline"]}
+        for k in ("cpu_baseline", "parity_check"):
+            if k in w:
+                out[k] = w[k]
+        ok = out.get("parity_check", {}).get("ok", True)
         print(json.dumps(out), flush=True)
-    if nranks > 1 or force_dist:
+    else:
+        w = time_render(ctx, args.workload, args.steps, args.warmup, spp_override=args.spp)
+        extras, config5 = [], None
+        if not args.no_extra and args.workload == "cornell-box" and args.spp == 0:
+            if nranks > 1:
+                # BASELINE config 5: bathroom2 spp 500 depth 50, tiles over the ranks + RCCL reduce
+                config5 = time_render(ctx, "bathroom2-spp500", max(1, min(args.steps, 3)), 1, with_cpu=False)
+            else:
+                for name in EXTRA_AT_N1:
+                    if name in RAY_WORKLOADS:
+                        extras.append(time_rays(ctx, name, 5, 1))
+                    else:
+                        extras.append(time_render(ctx, name, 2 if name == "veach-mis" else 3, 1, cpu_target_s=3.0))
+        if rank == 0:
+            rf = w["roofline"]
+            out = {
+                "metric": "Mrays/s (primary+secondary) at fixed spp; s/frame in ms_per_step",
+                "value": w["value"],
+                "unit": "Mrays/s",
+                "n_gpus": nranks,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "ms_per_step": w["ms_per_step"],
+                "higher_is_better": True,
+                "scaling": "strong",
+                "vs_baseline": None,
+                "dtype": "f64",
+                "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
+                "config": {
+                    "workload": w["config"],
+                    "parallelism": f"{w['tile_size']}x{w['tile_size']} tiles dealt diagonally over {nranks} GPU(s)"
+                                   + ("; frames pipelined on 2 streams" if w["pipelined"] else "")
+                                   + (" + RCCL reduce(sum) of fp32 framebuffer" if nranks > 1 else ""),
+                    "mpaths_per_s": w["mpaths_per_s"],
+                    "rays_per_frame": w["rays_per_frame"],
+                    "s_per_frame": round(w["ms_per_step"] / 1e3, 4),
+                },
+                "roofline": rf,
+            }
+            for k in ("cpu_baseline", "parity_check", "assembled_equals_single_rank"):
+                if k in w:
+                    out[k] = w[k]
+            if config5 is not None:
+                out["config5"] = config5
+            if extras:
+                out["workloads"] = extras
+            checks = [w] + extras + ([config5] if config5 else [])
+            ok = all(x.get("parity_check", {}).get("ok", True) and x.get("assembled_equals_single_rank", True) for x in checks)
+            out["checks_ok"] = ok
+            print(json.dumps(out), flush=True)
+    if in_group:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if rehearsal else "cuda")
+        dist.broadcast(flag, src=0)
+        ok = bool(int(flag[0]))
         dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        raise SystemExit("bench.py: a parity / assembly check failed (see parity_check / assembled_equals_single_rank)")
 
 
 if __name__ == "__main__":

@@ -607,10 +607,10 @@ __global__ void k_tonemap(const float* __restrict__ in, size_t n, uint8_t* __res
 // ------------------------------------------------------------------------------------------- launchers
 namespace prt {
 
-// The compiled permutations: lean, textures only, Phong only, everything.  A scene gets the smallest one
+// The compiled permutations: lean, textures only, Phong only, CookTorrance only, everything.  A scene gets the smallest one
 // that covers its materials.
 int render_permutation(int feat) {
-    if (feat == 0 || feat == PRT_FEAT_TEX || feat == PRT_FEAT_PHONG) return feat;
+    if (feat == 0 || feat == PRT_FEAT_TEX || feat == PRT_FEAT_PHONG || feat == PRT_FEAT_CT) return feat;
     return PRT_FEAT_ALL;
 }
 
@@ -630,6 +630,7 @@ static RenderKernel render_kernel(bool count, int feat, bool llds) {
     case 0: return render_kernel_feat<0>(count, llds);
     case PRT_FEAT_TEX: return render_kernel_feat<PRT_FEAT_TEX>(count, llds);
     case PRT_FEAT_PHONG: return render_kernel_feat<PRT_FEAT_PHONG>(count, llds);
+    case PRT_FEAT_CT: return render_kernel_feat<PRT_FEAT_CT>(count, llds);
     default: return render_kernel_feat<PRT_FEAT_ALL>(count, llds);
     }
 }

@@ -13,7 +13,7 @@
 #include <stdint.h>
 
 #ifndef PRT_BVH_WIDTH
-#define PRT_BVH_WIDTH 2      // children per node: 2 (32-byte nodes) or 4 (64-byte nodes, collapsed from the same binary tree)
+#define PRT_BVH_WIDTH 4      // children per node: 4 (64-byte nodes, collapsed from the binary tree; measured +11...32 %) or 2 (32-byte nodes)
 #endif
 #ifndef PRT_STACK_DEPTH
 #define PRT_STACK_DEPTH 32   // LDS traversal stack entries per lane; the builders bound the stack a traversal can need to it

@@ -190,14 +190,21 @@ def box(lo, hi):
 
 
 # --------------------------------------------------------------------------------------- S1
-def cornell_box(ball_subdiv=5, width=1024, height=1024, symmetric_camera=False) -> SceneData:
-    """S1: open-front box [-1,1]^3, ceiling quad light (17,12,4), tessellated DiffuseBall."""
+def cornell_box(ball_subdiv=5, width=1024, height=1024, symmetric_camera=False, ball_cooktorrance_alpha=None) -> SceneData:
+    """S1: open-front box [-1,1]^3, ceiling quad light (17,12,4), tessellated DiffuseBall.
+    `ball_cooktorrance_alpha`: the ball becomes a CookTorrance conductor with that roughness and the loader's
+    default gold eta / k (Source/Model.cpp:306-315) — the configuration behind the reference's published
+    Results/cornell-box_..._alpha0.1.png."""
     b = _Builder("cornell-box")
     white = b.material(Material("DiffuseWhite", _abi.MAT_LAMBERTIAN, kd=(0.725, 0.71, 0.68)))
     red = b.material(Material("LeftWall", _abi.MAT_LAMBERTIAN, kd=(0.63, 0.065, 0.05)))
     green = b.material(Material("RightWall", _abi.MAT_LAMBERTIAN, kd=(0.14, 0.45, 0.091)))
     light = b.material(Material("Light", _abi.MAT_DIFFUSE_LIGHT, emission=(17.0, 12.0, 4.0)))
-    ball = b.material(Material("DiffuseBall", _abi.MAT_LAMBERTIAN, kd=(0.5, 0.5, 0.8)))
+    if ball_cooktorrance_alpha is None:
+        ball = b.material(Material("DiffuseBall", _abi.MAT_LAMBERTIAN, kd=(0.5, 0.5, 0.8)))
+    else:
+        ball = b.material(Material("DiffuseBall", _abi.MAT_COOKTORRANCE, kd=(0.5, 0.5, 0.8), eta=(0.1, 0.5, 1.5), k=(4.0, 0.02, 0.3),
+                                   alpha_x=ball_cooktorrance_alpha, alpha_y=ball_cooktorrance_alpha))
     b.mesh("floor", white, *quad((-1, -1, 1), (1, -1, 1), (1, -1, -1), (-1, -1, -1)))
     b.mesh("ceiling", white, *quad((-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1)))
     b.mesh("backWall", white, *quad((-1, -1, -1), (1, -1, -1), (1, 1, -1), (-1, 1, -1)))

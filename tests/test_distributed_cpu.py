@@ -58,3 +58,26 @@ def test_tile_owner_map_partitions_image():
         assert counts.sum() == w * h
         if w * h >= 1024 * 720:  # round-robin tiles balance the big frames to within one tile row
             assert counts.max() - counts.min() <= tile * tile * 2
+
+
+def test_bench_launcher_starts_one_rank_per_gpu():
+    """`python bench.py --gpus N` with WORLD_SIZE unset must itself start N ranks: the launcher
+    path is driven with PRT_BENCH_LAUNCH_STUB=1, which makes every rank report its environment instead of touching a
+    GPU.  Also: a rank count that disagrees with --gpus is refused, and --gpus 1 stays a single process."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PRT_BENCH_LAUNCH_STUB"] = "1"
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "3", "--steps", "1"], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert sorted(x["rank"] for x in lines) == [0, 1, 2]
+    assert all(x["n_gpus"] == 3 and x["master"] == "127.0.0.1" for x in lines)
+    assert len({x["port"] for x in lines}) == 1
+    r = subprocess.run([sys.executable, bench, "--gpus", "1"], capture_output=True, text=True, env=env, timeout=120)
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1 and lines[0]["n_gpus"] == 1
+    # ranks started by someone else with the wrong world size: refused, not silently run as 1 GPU
+    r = subprocess.run([sys.executable, bench, "--gpus", "8"], capture_output=True, text=True, env=dict(env, WORLD_SIZE="2", RANK="0"), timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

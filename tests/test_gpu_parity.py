@@ -486,3 +486,103 @@ def test_scaled_and_translated_scene_hits(gpu, scale, offset):
     check(sc.trace_closest(rays))
     # the device-built tree obeys the same bounds
     check(api.Scene(data, device_bvh=True).upload(gpu).trace_closest(rays))
+
+
+def test_failed_upload_leaves_scene_unusable_but_sane(gpu, monkeypatch):
+    """a failure in the middle of prt_scene_upload must not leave a half-filled device scene behind
+    (prt_sample_lights would launch on null tables).  PRT_TEST_FAIL_UPLOAD=k makes the k-th table upload report
+    out-of-memory; afterwards every compute call must refuse cleanly and a later upload must work."""
+    data = scenes.tiny_scene()
+    sc = api.Scene(data)
+    for k in (0, 2, 4, 6):
+        monkeypatch.setenv("PRT_TEST_FAIL_UPLOAD", str(k))
+        with pytest.raises(api.PrtError) as e:
+            sc.upload(0)
+        assert e.value.code == _abi.PRT_E_OOM
+        for call in (lambda: sc.sample_lights(np.zeros((4, 3))), lambda: sc.render(spp=1), lambda: sc.trace_closest(np.zeros(1, dtype=_abi.RAY_DTYPE))):
+            with pytest.raises(api.PrtError) as e2:
+                call()
+            assert e2.value.code == _abi.PRT_E_NO_DEVICE
+    monkeypatch.delenv("PRT_TEST_FAIL_UPLOAD")
+    sc.upload(0)
+    img = sc.render(spp=2, max_depth=4, seed=3)
+    ref, _ = oracle.Oracle(data).render(spp=2, max_depth=4, seed=3)
+    compare_images(img, ref)
+    # the same for a device-built tree (its staging copies are freed on every path)
+    sd = api.Scene(data, device_bvh=True)
+    monkeypatch.setenv("PRT_TEST_FAIL_UPLOAD", "1")
+    with pytest.raises(api.PrtError):
+        sd.upload(0)
+    monkeypatch.delenv("PRT_TEST_FAIL_UPLOAD")
+    sd.upload(0)
+    compare_images(sd.render(spp=2, max_depth=4, seed=3), ref)
+
+
+def test_negative_max_depth_renders_black(gpu):
+    """Camera.cpp:121: RayColor returns 0 when depth < 0, before tracing anything — maxDepth < 0 is a black frame
+    (and not the camera-ray emission / background the kernel would otherwise add)."""
+    data = scenes.tiny_scene()
+    sc = api.Scene(data).upload(0)
+    img = sc.render(spp=3, max_depth=-1, seed=1, background=(0.3, 0.2, 0.1))
+    ref, _ = oracle.Oracle(data).render(spp=3, max_depth=-1, seed=1, background=(0.3, 0.2, 0.1))
+    assert not img.any() and not ref.any()
+    assert sc.counters()["rays_closest"] == 0
+    # depth 0 still traces the camera ray
+    img0 = sc.render(spp=3, max_depth=0, seed=1, background=(0.3, 0.2, 0.1))
+    ref0, _ = oracle.Oracle(data).render(spp=3, max_depth=0, seed=1, background=(0.3, 0.2, 0.1))
+    compare_images(img0, ref0)
+    assert img0.any()
+
+
+def test_three_calls_in_flight_on_three_streams(gpu):
+    """the asynchronous entry points alternate two per-call slots; a third call in flight (three streams,
+    or a trace call between two pipelined renders) must wait for the call that last used its slot instead of
+    resetting that call's work counter under it.  Three frames with different seeds on three streams, plus a ray
+    batch in between, must equal the same frames rendered one at a time."""
+    import torch
+    data = scenes.cornell_box(ball_subdiv=2, width=256, height=256)
+    sc = api.Scene(data).upload(0)
+    cam = data.camera
+    seeds = (11, 12, 13)
+    want = []
+    for s in seeds:
+        fb = torch.zeros((cam.height, cam.width, 3), dtype=torch.float64, device="cuda")
+        sc.render_device(fb.data_ptr(), None, spp=24, max_depth=6, seed=s)
+        torch.cuda.synchronize()
+        want.append(fb.cpu().numpy())
+    lo, hi = data.bounds()
+    rays = scenes.random_rays(1 << 16, lo, hi, seed=5)
+    d_r = torch.from_numpy(rays.view(np.float64).reshape(-1, 8)).cuda()
+    d_h = torch.zeros((rays.shape[0], 4), dtype=torch.float64, device="cuda")
+    sc.trace_closest_device(d_r.data_ptr(), rays.shape[0], d_h.data_ptr())
+    torch.cuda.synchronize()
+    hits_want = d_h.cpu().numpy().copy()
+    for rep in range(3):
+        streams = [torch.cuda.Stream() for _ in seeds]
+        fbs = [torch.zeros((cam.height, cam.width, 3), dtype=torch.float64, device="cuda") for _ in seeds]
+        d_h.zero_()
+        torch.cuda.synchronize()
+        for k, (s, st, fb) in enumerate(zip(seeds, streams, fbs)):
+            with torch.cuda.stream(st):
+                sc.render_device(fb.data_ptr(), None, spp=24, max_depth=6, seed=s, stream=st.cuda_stream)
+                if k == 0:
+                    sc.trace_closest_device(d_r.data_ptr(), rays.shape[0], d_h.data_ptr(), stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        for fb, w in zip(fbs, want):
+            assert np.array_equal(fb.cpu().numpy(), w)
+        assert np.array_equal(d_h.cpu().numpy(), hits_want)
+
+
+def test_counters_report_the_tree_that_is_resident(gpu):
+    """prt_get_counters' static fields follow the tree in use, host- or device-built (r1: bvh_nodes was 0 for device builds)."""
+    data = scenes.cornell_box(ball_subdiv=2, width=64, height=64)
+    for dev in (False, True):
+        sc = api.Scene(data, device_bvh=dev).upload(0)
+        sc.render(spp=1, max_depth=2)
+        c, info = sc.counters(), sc.bvh_info()
+        assert c["bvh_nodes"] == info["n_nodes"] > 0 and c["bvh_depth"] == info["depth"] > 0
+        assert info["built_on_device"] == int(dev) and info["node_bytes"] in (32, 64) and info["width"] in (2, 4)
+        lo, hi = data.bounds()
+        sc.trace_closest(scenes.random_rays(5000, lo, hi, seed=3), count_work=True)
+        c = sc.counters()
+        assert 0 < c["tri_full"] <= c["tri_tests"]

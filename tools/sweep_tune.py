@@ -1,0 +1,26 @@
+"""Developer tool: sweep the wave-scheduling thresholds of K3 (PRT_TUNE_KEEP / LEAF_BATCH / INNER_MIN are read by
+prt_render_device at every call) for one library build, on the three render scenes at reduced spp."""
+import itertools, os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+from pooraytracer_amd import api, scenes
+tag = os.environ.get("PRT_LIB", "default").split("libprt_")[-1]
+keeps = [int(x) for x in os.environ.get("SW_KEEP", "16,20,24,28,32").split(",")]
+lbs = [int(x) for x in os.environ.get("SW_LB", "32").split(",")]
+ims = [int(x) for x in os.environ.get("SW_IM", "12").split(",")]
+for name, fn, spp, depth in (("cornell", scenes.cornell_box, 125, 20), ("bathroom", scenes.bathroom, 50, 50), ("veach", scenes.veach_mis, 200, 100)):
+    data = fn(); sc = api.Scene(data).upload(0); cam = data.camera
+    fb = torch.zeros((cam.height, cam.width, 3), dtype=torch.float32, device="cuda")
+    sc.render_device(None, fb.data_ptr(), spp=4, max_depth=depth); torch.cuda.synchronize()
+    res = []
+    for k, lb, im in itertools.product(keeps, lbs, ims):
+        os.environ["PRT_TUNE_KEEP"], os.environ["PRT_TUNE_LEAF_BATCH"], os.environ["PRT_TUNE_INNER_MIN"] = str(k), str(lb), str(im)
+        best = 1e9
+        for _ in range(2):
+            sc.render_device(None, fb.data_ptr(), max_depth=depth, spp=spp); torch.cuda.synchronize()
+            c = sc.counters(); best = min(best, c["kernel_ms"])
+        r = c["rays_closest"] + c["rays_shadow"]
+        res.append((r / best / 1e3, k, lb, im))
+    res.sort(reverse=True)
+    print(tag, name, " ".join(f"{m:.0f}@k{k}/lb{lb}/im{im}" for m, k, lb, im in res[:12]), "| worst", f"{res[-1][0]:.0f}", flush=True)
+    del sc
