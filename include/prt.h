@@ -90,6 +90,12 @@ typedef struct PrtSceneDesc {
     uint32_t n_textures;
     uint32_t flags;          /* PRT_SCENE_* bits; 0 = defaults */
     const PrtTexture* textures;
+    /* The `lights` argument of Camera::Render(world, lights) (Source/Camera.h:27): indices of the meshes that were
+     * added to the lights list, in that order.  NULL = what main.cpp:40-45 builds — every mesh whose material
+     * HasEmission(), in mesh order.  A non-NULL pointer with n_light_meshes == 0 is an empty list (no NEE). */
+    const int32_t* light_meshes;
+    uint32_t n_light_meshes;
+    uint32_t reserved;
 } PrtSceneDesc;
 
 /* Build the traversal BVH on the GPU at prt_scene_upload time instead of on the host at create time
@@ -183,13 +189,17 @@ int prt_device_count(int* n);
 
 int prt_scene_create(const PrtSceneDesc* desc, PrtScene** out);
 void prt_scene_destroy(PrtScene* scene);
-/* Build + flatten the BVH on the host and upload SoA nodes / triangles / materials / light tree. */
+/* Upload nodes / triangles / materials / textures / light tree to `device` (the tree was built in prt_scene_create on
+ * the host, or is built here on the GPU with PRT_SCENE_DEVICE_BVH).  All or nothing: on failure nothing stays resident
+ * and the scene is back in the not-uploaded state. */
 int prt_scene_upload(PrtScene* scene, int device);
 
 /* New vertex positions ([n_tris][3][xyz], same layout as PrtSceneDesc.vertices; normals may be NULL) for a
  * scene whose topology, materials and texture coordinates stay as created: re-runs the Triangle constructor
  * precompute and the light tree; on an uploaded scene the BVH is REBUILT on the GPU (PRT_SCENE_DEVICE_BVH
- * path: 4 ms per 126k triangles, 17 ms per 8M), which is what a refit would be for, without its quality decay. */
+ * path: 4 ms per 126k triangles, 17 ms per 8M).  Limitation: there is no topology-preserving refit (the
+ * reference has none either — it rebuilds, Source/BVH.cpp:7-48); a caller that moves geometry every frame pays
+ * the rebuild plus a re-upload of the triangle records each time. */
 int prt_scene_update_vertices(PrtScene* scene, const double* vertices, const double* normals);
 
 /* Number of light triangles and their order in the reference's area-CDF descent (BVH.cpp:86-100). */
@@ -209,12 +219,32 @@ int prt_sample_lights(PrtScene* scene, const double* origins, size_t n, uint64_t
                       PrtLightSample* out);
 
 /*
+ * Test hooks for the material arithmetic K3 shades with (the device functions themselves, on caller-supplied
+ * directions).  Item i draws from the stream keyed (seed, i, 0).  `material` / `texture` index the scene's tables.
+ *   prt_material_eval     Material::Eval(wi, ctx{wo, uv}), wi / wo LOCAL (z = shading normal):
+ *                         Lambertian Material.h:128-130, PhoneReflectance :227-248 (draws one number), CookTorrance :474-496
+ *   prt_material_scatter  Material::Scatter(Ray(0, rd_i), record{normal, tangent, uv}) (Material.h:131-151,263-285,
+ *                         344-363,497-516): scattered direction in WORLD space, attenuation = f cos / pdf, ok = its return value
+ *   prt_texture_value     ImageTexture::Value(u, v) (Texture.cpp:22-49)
+ * uv may be NULL (all zero).
+ */
+int prt_material_eval(PrtScene* scene, int32_t material, size_t n, const double* wi, const double* wo, const double* uv,
+                      uint64_t seed, double* f);
+int prt_material_scatter(PrtScene* scene, int32_t material, size_t n, const double* rd, const double* normal,
+                         const double* tangent, const double* uv, uint64_t seed, double* wi_world, double* attenuation,
+                         int32_t* ok);
+int prt_texture_value(PrtScene* scene, int32_t texture, size_t n, const double* uv, double* rgb);
+
+/*
  * K3+K5: render one frame.  rgb_f64 / rgb_f32 are W*H*3 row-major host buffers (either may be
  * NULL).  Pixels of tiles owned by other ranks are written as 0 so a sum over ranks is exact.
  */
 int prt_render(PrtScene* scene, const PrtCamera* cam, const PrtRenderParams* params,
                double* rgb_f64, float* rgb_f32);
-/* Same, outputs are device pointers on the scene's device; asynchronous on hip_stream. */
+/* Same, outputs are device pointers on the scene's device; asynchronous on hip_stream.  A scene keeps two sets of
+ * per-call state (counters, partial sums, events): two calls — render or trace — may be in flight at once on different
+ * streams; a third one first waits (on its stream) for the call that last used its set.  A PrtScene is not thread-safe:
+ * issue its calls from one host thread. */
 int prt_render_device(PrtScene* scene, const PrtCamera* cam, const PrtRenderParams* params,
                       void* d_rgb_f64, void* d_rgb_f32, int count_work, void* hip_stream);
 

@@ -53,6 +53,9 @@ typedef struct OrcSceneDesc {
     uint32_t n_textures;
     uint32_t reserved;
     const OrcTexture* textures;
+    const int32_t* light_meshes; /* the `lights` list as mesh indices, NULL = every emissive mesh in mesh order (main.cpp:40-45) */
+    uint32_t n_light_meshes;
+    uint32_t reserved2;
 } OrcSceneDesc;
 
 typedef struct OrcCamera {
@@ -131,6 +134,23 @@ void orc_render(const OrcScene*, const OrcCamera*, const OrcRenderParams*, doubl
 /* per-sample radiance of selected pixels: out[n_pixels][spp][3]. */
 void orc_render_samples(const OrcScene*, const OrcCamera*, const OrcRenderParams*,
                         const int32_t* pixel_xy, size_t n_pixels, double* out);
+/* Material / texture hooks for the known-answer tests.  Directions are LOCAL (z = shading normal) for eval and the
+ * CookTorrance terms, WORLD for scatter; item i uses the stream keyed (seed, i, 0).
+ *   orc_material_eval      Material::Eval(wi, ctx{wo, uv})                              -> f[n][3]
+ *   orc_material_scatter   Material::Scatter(Ray(0, rd_i), record{normal, tangent, uv}) -> scattered direction (world),
+ *                          attenuation = f cos / pdf, ok = Scatter's return value
+ *   orc_texture_value      ImageTexture::Value(u, v)
+ *   orc_cooktorrance_terms {D(wm), Lambda(w), G1(w), D(w, wm)} and Fresnel(|w . wm|) per channel
+ *   orc_frame              Material::WorldToLocal / LocalToWorld */
+void orc_material_eval(const OrcScene*, int32_t material, size_t n, const double* wi, const double* wo, const double* uv,
+                       uint64_t seed, double* f);
+void orc_material_scatter(const OrcScene*, int32_t material, size_t n, const double* rd, const double* normal,
+                          const double* tangent, const double* uv, uint64_t seed, double* wi_world, double* attenuation,
+                          int32_t* ok);
+void orc_texture_value(const OrcScene*, int32_t texture, size_t n, const double* uv, double* rgb);
+void orc_cooktorrance_terms(const OrcScene*, int32_t material, size_t n, const double* w, const double* wm, double* out4,
+                            double* fresnel3);
+void orc_frame(const double* normal, const double* tangent, size_t n, const double* in, int to_local, double* out);
 /* camera rays (origin, unnormalised direction) for all pixels: out[H][W][6] (Camera.cpp:75-117). */
 void orc_camera_rays(const OrcCamera*, double* out);
 

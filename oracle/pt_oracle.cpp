@@ -953,8 +953,18 @@ OrcScene* orc_scene_create(const OrcSceneDesc* d) {
         for (uint64_t t = d->mesh_first_tri[m]; t < d->mesh_first_tri[m + 1]; ++t) objs.push_back(Ref{0, (int)t});
         if (objs.empty()) continue;
         worldList.push_back(Ref{1, sc.Build(objs, 0, objs.size())});
-        if (sc.mats[d->mesh_material[m]].HasEmission()) lightList.push_back(Ref{1, sc.Build(objs, 0, objs.size())});
+        // main.cpp:40-41; with an explicit lights list (Camera::Render's second argument) the list decides instead
+        if (!d->light_meshes && sc.mats[d->mesh_material[m]].HasEmission()) lightList.push_back(Ref{1, sc.Build(objs, 0, objs.size())});
     }
+    if (d->light_meshes)
+        for (uint32_t k = 0; k < d->n_light_meshes; ++k) {
+            const uint32_t m = (uint32_t)d->light_meshes[k];
+            std::vector<Ref> objs;
+            for (uint64_t t = d->mesh_first_tri[m]; t < d->mesh_first_tri[m + 1]; ++t) objs.push_back(Ref{0, (int)t});
+            if (objs.empty()) continue;
+            sc.Build(objs, 0, objs.size()); // the world's BVHNode(mesh) sorted the mesh's list first (BVH.cpp:33)
+            lightList.push_back(Ref{1, sc.Build(objs, 0, objs.size())});
+        }
     if (!worldList.empty()) sc.world = Ref{1, sc.Build(worldList, 0, worldList.size())};
     if (!lightList.empty()) {
         sc.lights = Ref{1, sc.Build(lightList, 0, lightList.size())};
@@ -1069,6 +1079,83 @@ void orc_render_samples(const OrcScene* h, const OrcCamera* c, const OrcRenderPa
             double* o = out + (k * cam.samplesPerPixel + s) * 3;
             o[0] = r.x; o[1] = r.y; o[2] = r.z;
         }
+    }
+}
+
+// ---- material / texture hooks for the known-answer tests (same shapes as prt_material_* / prt_texture_value)
+void orc_material_eval(const OrcScene* h, int32_t material, size_t n, const double* wi, const double* wo, const double* uv,
+                       uint64_t seed, double* f) {
+    const Material& m = h->sc.mats[material];
+    for (size_t i = 0; i < n; ++i) {
+        g_rng.seed(seed, i, 0);
+        MaterialEvalContext c;
+        c.p = V3{0, 0, 0};
+        c.uv = uv ? V2{uv[i * 2], uv[i * 2 + 1]} : V2{0, 0};
+        c.wo = V3{wo[i * 3], wo[i * 3 + 1], wo[i * 3 + 2]};
+        c.n = V3{0, 0, 1};
+        c.dpdus = V3{1, 0, 0};
+        V3 r = m.Eval(V3{wi[i * 3], wi[i * 3 + 1], wi[i * 3 + 2]}, c);
+        f[i * 3] = r.x; f[i * 3 + 1] = r.y; f[i * 3 + 2] = r.z;
+    }
+}
+
+void orc_material_scatter(const OrcScene* h, int32_t material, size_t n, const double* rd, const double* normal,
+                          const double* tangent, const double* uv, uint64_t seed, double* wi_world, double* attenuation,
+                          int32_t* ok) {
+    const Material& m = h->sc.mats[material];
+    for (size_t i = 0; i < n; ++i) {
+        g_rng.seed(seed, i, 0);
+        HitRecord rec;
+        rec.position = V3{0, 0, 0};
+        rec.normal = V3{normal[0], normal[1], normal[2]};
+        rec.tangent = V3{tangent[0], tangent[1], tangent[2]};
+        rec.uv = uv ? V2{uv[i * 2], uv[i * 2 + 1]} : V2{0, 0};
+        Ray in{V3{0, 0, 0}, V3{rd[i * 3], rd[i * 3 + 1], rd[i * 3 + 2]}};
+        V3 att{0, 0, 0};
+        Ray out{V3{0, 0, 0}, V3{0, 0, 0}};
+        const bool good = m.Scatter(in, rec, att, out);
+        ok[i] = good ? 1 : 0;
+        wi_world[i * 3] = good ? out.direction.x : 0; wi_world[i * 3 + 1] = good ? out.direction.y : 0; wi_world[i * 3 + 2] = good ? out.direction.z : 0;
+        attenuation[i * 3] = good ? att.x : 0; attenuation[i * 3 + 1] = good ? att.y : 0; attenuation[i * 3 + 2] = good ? att.z : 0;
+    }
+}
+
+void orc_texture_value(const OrcScene* h, int32_t texture, size_t n, const double* uv, double* rgb) {
+    const Texture& t = h->sc.texs[texture];
+    for (size_t i = 0; i < n; ++i) {
+        V3 c = t.Value(uv[i * 2], uv[i * 2 + 1]);
+        rgb[i * 3] = c.x; rgb[i * 3 + 1] = c.y; rgb[i * 3 + 2] = c.z;
+    }
+}
+
+// CookTorrance building blocks of one material: out[i] = {D(wm), Lambda(w), G1(w), D(w, wm)} and the conductor
+// Fresnel term per channel for cos_i = |w . wm| (Material.h:373-411, MaterialUtils.h:100-111)
+void orc_cooktorrance_terms(const OrcScene* h, int32_t material, size_t n, const double* w, const double* wm, double* out4,
+                            double* fresnel3) {
+    const Material& m = h->sc.mats[material];
+    for (size_t i = 0; i < n; ++i) {
+        const V3 a{w[i * 3], w[i * 3 + 1], w[i * 3 + 2]}, b{wm[i * 3], wm[i * 3 + 1], wm[i * 3 + 2]};
+        out4[i * 4] = m.D(b);
+        out4[i * 4 + 1] = m.Lambda(a);
+        out4[i * 4 + 2] = m.G1(a);
+        out4[i * 4 + 3] = m.Dv(a, b);
+        const V3 F = m.Fresnel(a, b);
+        fresnel3[i * 3] = F.x; fresnel3[i * 3 + 1] = F.y; fresnel3[i * 3 + 2] = F.z;
+    }
+}
+
+// Material::WorldToLocal (to_local != 0) / LocalToWorld (Material.h:76-98) in the frame (normal, tangent)
+void orc_frame(const double* normal, const double* tangent, size_t n, const double* in, int to_local, double* out) {
+    HitRecord rec;
+    rec.normal = V3{normal[0], normal[1], normal[2]};
+    rec.tangent = V3{tangent[0], tangent[1], tangent[2]};
+    MaterialEvalContext c;
+    c.n = rec.normal;
+    c.dpdus = rec.tangent;
+    for (size_t i = 0; i < n; ++i) {
+        const V3 v{in[i * 3], in[i * 3 + 1], in[i * 3 + 2]};
+        const V3 r = to_local ? Material::WorldToLocal(v, rec) : Material::LocalToWorld(v, c);
+        out[i * 3] = r.x; out[i * 3 + 1] = r.y; out[i * 3 + 2] = r.z;
     }
 }
 

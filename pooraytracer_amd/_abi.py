@@ -64,6 +64,9 @@ class PrtSceneDesc(C.Structure):
         ("n_textures", C.c_uint32),
         ("flags", C.c_uint32),
         ("textures", C.c_void_p),
+        ("light_meshes", C.c_void_p),
+        ("n_light_meshes", C.c_uint32),
+        ("reserved", C.c_uint32),
     ]
 
 
@@ -185,6 +188,9 @@ EXPORTS = [
     "prt_render_device",
     "prt_get_counters",
     "prt_tonemap_srgb8",
+    "prt_material_eval",
+    "prt_material_scatter",
+    "prt_texture_value",
 ]
 
 
@@ -229,6 +235,13 @@ def marshal_scene(scene, desc_cls=PrtSceneDesc, mat_cls=PrtMaterial, tex_cls=Prt
     d.materials = C.addressof(mats)
     d.n_textures = len(scene.textures)
     d.textures = C.addressof(texs)
+    lm = getattr(scene, "light_meshes", None)  # the `lights` list of Camera::Render as mesh indices; None = main.cpp's
+    if lm is not None:
+        arr = np.ascontiguousarray(lm, dtype=np.int32).reshape(-1)
+        buf = (C.c_int32 * max(1, arr.size))(*arr.tolist())
+        keep.append(buf)
+        d.light_meshes = C.addressof(buf)
+        d.n_light_meshes = arr.size
     return d, keep
 
 

@@ -60,6 +60,9 @@ def load():
     L.prt_render_device.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     L.prt_get_counters.argtypes = [vp, vp]
     L.prt_tonemap_srgb8.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.prt_material_eval.argtypes = [vp, i32, sz, vp, vp, vp, u64, vp]
+    L.prt_material_scatter.argtypes = [vp, i32, sz, vp, vp, vp, vp, u64, vp, vp, vp]
+    L.prt_texture_value.argtypes = [vp, i32, sz, vp, vp]
     if L.prt_abi_version() != _abi.PRT_ABI_VERSION:
         raise PrtError(-101, "ABI version mismatch between _abi.py and libprt_hip.so")
     _lib = L
@@ -69,6 +72,10 @@ def load():
 def _check(rc):
     if rc != 0:
         raise PrtError(rc, load().prt_last_error().decode("utf-8", "replace"))
+
+
+def _f64(a, k):
+    return np.ascontiguousarray(a, dtype=np.float64).reshape(-1, k)
 
 
 def device_count():
@@ -141,6 +148,31 @@ class Scene:
         origins = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
         out = np.zeros(origins.shape[0], dtype=_abi.LIGHT_SAMPLE_DTYPE)
         _check(load().prt_sample_lights(self._h, origins.ctypes.data, origins.shape[0], seed, out.ctypes.data))
+        return out
+
+    # ---- test hooks for the material arithmetic (include/prt.h)
+    def material_eval(self, material, wi, wo, uv=None, seed=1):
+        wi, wo = _f64(wi, 3), _f64(wo, 3)
+        uv = None if uv is None else _f64(uv, 2)
+        out = np.zeros_like(wi)
+        _check(load().prt_material_eval(self._h, material, wi.shape[0], wi.ctypes.data, wo.ctypes.data,
+                                        None if uv is None else uv.ctypes.data, seed, out.ctypes.data))
+        return out
+
+    def material_scatter(self, material, rd, normal=(0, 0, 1), tangent=(1, 0, 0), uv=None, seed=1):
+        rd = _f64(rd, 3)
+        uv = None if uv is None else _f64(uv, 2)
+        nrm, tan = _f64(normal, 3), _f64(tangent, 3)
+        wi, att, ok = np.zeros_like(rd), np.zeros_like(rd), np.zeros(rd.shape[0], dtype=np.int32)
+        _check(load().prt_material_scatter(self._h, material, rd.shape[0], rd.ctypes.data, nrm.ctypes.data, tan.ctypes.data,
+                                           None if uv is None else uv.ctypes.data, seed, wi.ctypes.data, att.ctypes.data,
+                                           ok.ctypes.data))
+        return wi, att, ok.astype(bool)
+
+    def texture_value(self, texture, uv):
+        uv = _f64(uv, 2)
+        out = np.zeros((uv.shape[0], 3))
+        _check(load().prt_texture_value(self._h, texture, uv.shape[0], uv.ctypes.data, out.ctypes.data))
         return out
 
     def render(self, camera=None, f32=False, **kw):

@@ -28,6 +28,12 @@ void launch_finalize(const DCamera& C, const DRenderParams& P, const double* d_p
 void launch_sample_lights(const DScene& S, const double* d_origins, size_t n, uint64_t seed, PrtLightSample* d_out,
                           hipStream_t st);
 void launch_tonemap(const float* d_in, size_t n, uint8_t* d_out, hipStream_t st);
+void launch_material_eval(const DScene& S, int material, const double* wi, const double* wo, const double* uv, size_t n,
+                          uint64_t seed, double* out, hipStream_t st);
+void launch_material_scatter(const DScene& S, int material, const double* rd, const double* normal, const double* tangent,
+                             const double* uv, size_t n, uint64_t seed, double* wi_out, double* att_out, int32_t* ok_out,
+                             hipStream_t st);
+void launch_texture_value(const DScene& S, int texture, const double* uv, size_t n, double* out, hipStream_t st);
 void launch_gather_tris(const DTri* tri_in, const DTriShade* shade_in, const uint32_t* order, uint32_t n, DTri* tri_out,
                         DTriShade* shade_out, hipStream_t st);
 } // namespace prt
@@ -58,6 +64,8 @@ struct PrtScene {
     prt::BuiltBVH bvh;
     std::vector<uint64_t> mesh_first; // mesh structure, kept for prt_scene_update_vertices
     std::vector<int32_t> mesh_mat;
+    std::vector<int32_t> light_meshes; // PrtSceneDesc.light_meshes when given
+    bool explicit_lights = false;
     bool device_bvh = false; // PRT_SCENE_DEVICE_BVH: the tree is built in prt_scene_upload, on the GPU
     PrtBvhInfo bvh_info{};
     // device side
@@ -159,6 +167,10 @@ int prt_scene_create(const PrtSceneDesc* desc, PrtScene** out) {
     } else if (desc->n_tris) {
         return fail(PRT_E_INVALID, "prt_scene_create: triangles without meshes");
     }
+    if (desc->n_light_meshes && !desc->light_meshes) return fail(PRT_E_INVALID, "prt_scene_create: light_meshes is null");
+    for (uint32_t i = 0; i < (desc->light_meshes ? desc->n_light_meshes : 0u); ++i)
+        if (desc->light_meshes[i] < 0 || (uint32_t)desc->light_meshes[i] >= desc->n_meshes)
+            return fail(PRT_E_INVALID, "prt_scene_create: light_meshes entry out of range");
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
         const PrtMaterial& m = desc->materials[i];
         if (m.type < PRT_MAT_LAMBERTIAN || m.type > PRT_MAT_EMPTY)
@@ -175,6 +187,8 @@ int prt_scene_create(const PrtSceneDesc* desc, PrtScene** out) {
         prt::setup_triangles(*desc, s->tris);
         s->mesh_first.assign(desc->mesh_first_tri, desc->mesh_first_tri + (desc->n_meshes ? desc->n_meshes + 1 : 0));
         s->mesh_mat.assign(desc->mesh_material, desc->mesh_material + desc->n_meshes);
+        s->explicit_lights = desc->light_meshes != nullptr;
+        if (s->explicit_lights) s->light_meshes.assign(desc->light_meshes, desc->light_meshes + desc->n_light_meshes);
         prt::setup_materials(*desc, s->mats);
         s->texs.resize(desc->n_textures);
         for (uint32_t i = 0; i < desc->n_textures; ++i) {
@@ -449,6 +463,9 @@ int prt_scene_update_vertices(PrtScene* s, const double* vertices, const double*
         d.n_meshes = (uint32_t)s->mesh_mat.size();
         d.mesh_first_tri = s->mesh_first.data();
         d.mesh_material = s->mesh_mat.data();
+        static const int32_t none = 0;
+        d.light_meshes = s->explicit_lights ? (s->light_meshes.empty() ? &none : s->light_meshes.data()) : nullptr;
+        d.n_light_meshes = (uint32_t)s->light_meshes.size();
         s->lights = prt::LightTree();
         prt::build_light_tree(d, s->tris, s->mats, s->lights); // light areas and the CDF order follow the geometry
         if (s->device >= 0 && s->tris.size() >= 2) {
@@ -545,6 +562,85 @@ int prt_sample_lights(PrtScene* s, const double* origins, size_t n, uint64_t see
     (void)hipFree(dorg);
     (void)hipFree(dout);
     return rc;
+}
+
+namespace {
+// Device staging for the small host-buffer test hooks: copies inputs up, frees everything on destruction.
+struct HookBufs {
+    std::vector<void*> p;
+    ~HookBufs() {
+        for (void* q : p) (void)hipFree(q);
+    }
+    void* up(const void* src, size_t bytes) { // nullptr in -> nullptr out
+        if (!src) return nullptr;
+        void* d = nullptr;
+        if (hipMalloc(&d, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
+        p.push_back(d);
+        if (hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return d;
+    }
+    void* out(size_t bytes) {
+        void* d = nullptr;
+        if (hipMalloc(&d, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr;
+        p.push_back(d);
+        return d;
+    }
+};
+} // namespace
+
+int prt_material_eval(PrtScene* s, int32_t material, size_t n, const double* wi, const double* wo, const double* uv,
+                      uint64_t seed, double* f) {
+    int rc = require_uploaded(s, "prt_material_eval");
+    if (rc) return rc;
+    if (material < 0 || (size_t)material >= s->mats.size()) return fail(PRT_E_INVALID, "prt_material_eval: material index out of range");
+    if (n == 0) return PRT_OK;
+    if (!wi || !wo || !f) return fail(PRT_E_INVALID, "prt_material_eval: null buffer");
+    HookBufs b;
+    const double *dwi = static_cast<const double*>(b.up(wi, n * 24)), *dwo = static_cast<const double*>(b.up(wo, n * 24));
+    const double* duv = static_cast<const double*>(b.up(uv, n * 16));
+    double* df = static_cast<double*>(b.out(n * 24));
+    if (!dwi || !dwo || !df || (uv && !duv)) return fail(PRT_E_OOM, "prt_material_eval: device staging failed");
+    prt::launch_material_eval(s->d, material, dwi, dwo, duv, n, seed, df, nullptr);
+    PRT_HIP(hipDeviceSynchronize());
+    PRT_HIP(hipMemcpy(f, df, n * 24, hipMemcpyDeviceToHost));
+    return PRT_OK;
+}
+
+int prt_material_scatter(PrtScene* s, int32_t material, size_t n, const double* rd, const double* normal, const double* tangent,
+                         const double* uv, uint64_t seed, double* wi_world, double* attenuation, int32_t* ok) {
+    int rc = require_uploaded(s, "prt_material_scatter");
+    if (rc) return rc;
+    if (material < 0 || (size_t)material >= s->mats.size()) return fail(PRT_E_INVALID, "prt_material_scatter: material index out of range");
+    if (n == 0) return PRT_OK;
+    if (!rd || !normal || !tangent || !wi_world || !attenuation || !ok) return fail(PRT_E_INVALID, "prt_material_scatter: null buffer");
+    HookBufs b;
+    const double* drd = static_cast<const double*>(b.up(rd, n * 24));
+    const double* duv = static_cast<const double*>(b.up(uv, n * 16));
+    double *dwi = static_cast<double*>(b.out(n * 24)), *datt = static_cast<double*>(b.out(n * 24));
+    int32_t* dok = static_cast<int32_t*>(b.out(n * 4));
+    if (!drd || !dwi || !datt || !dok || (uv && !duv)) return fail(PRT_E_OOM, "prt_material_scatter: device staging failed");
+    prt::launch_material_scatter(s->d, material, drd, normal, tangent, duv, n, seed, dwi, datt, dok, nullptr);
+    PRT_HIP(hipDeviceSynchronize());
+    PRT_HIP(hipMemcpy(wi_world, dwi, n * 24, hipMemcpyDeviceToHost));
+    PRT_HIP(hipMemcpy(attenuation, datt, n * 24, hipMemcpyDeviceToHost));
+    PRT_HIP(hipMemcpy(ok, dok, n * 4, hipMemcpyDeviceToHost));
+    return PRT_OK;
+}
+
+int prt_texture_value(PrtScene* s, int32_t texture, size_t n, const double* uv, double* rgb) {
+    int rc = require_uploaded(s, "prt_texture_value");
+    if (rc) return rc;
+    if (texture < 0 || (size_t)texture >= s->texs.size()) return fail(PRT_E_INVALID, "prt_texture_value: texture index out of range");
+    if (n == 0) return PRT_OK;
+    if (!uv || !rgb) return fail(PRT_E_INVALID, "prt_texture_value: null buffer");
+    HookBufs b;
+    const double* duv = static_cast<const double*>(b.up(uv, n * 16));
+    double* d = static_cast<double*>(b.out(n * 24));
+    if (!duv || !d) return fail(PRT_E_OOM, "prt_texture_value: device staging failed");
+    prt::launch_texture_value(s->d, texture, duv, n, d, nullptr);
+    PRT_HIP(hipDeviceSynchronize());
+    PRT_HIP(hipMemcpy(rgb, d, n * 24, hipMemcpyDeviceToHost));
+    return PRT_OK;
 }
 
 int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* p, void* d_rgb_f64, void* d_rgb_f32,

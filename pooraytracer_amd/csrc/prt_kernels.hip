@@ -590,6 +590,40 @@ __global__ void k_sample_lights(DScene S, const double* __restrict__ origins, si
     out[i] = o;
 }
 
+// Test hooks for the material arithmetic (prt_material_eval / prt_material_scatter / prt_texture_value): the device
+// functions K3 shades with, on caller-supplied directions; item i draws from the stream keyed (seed, i, 0).
+__global__ void k_material_eval(DScene S, int material, const double* __restrict__ wi, const double* __restrict__ wo,
+                                const double* __restrict__ uv, size_t n, uint64_t seed, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng rng;
+    rng.seed(seed, i, 0);
+    const d2 t = uv ? d2{uv[i * 2], uv[i * 2 + 1]} : d2{0., 0.};
+    const d3 f = mat_eval<PRT_FEAT_ALL>(S, S.materials[material], ld3(wi + i * 3), ld3(wo + i * 3), t, rng);
+    out[i * 3] = f.x; out[i * 3 + 1] = f.y; out[i * 3 + 2] = f.z;
+}
+__global__ void k_material_scatter(DScene S, int material, const double* __restrict__ rd, d3 normal, d3 tangent,
+                                   const double* __restrict__ uv, size_t n, uint64_t seed, double* __restrict__ wi_out,
+                                   double* __restrict__ att_out, int32_t* __restrict__ ok_out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng rng;
+    rng.seed(seed, i, 0);
+    const Frame f{normal, tangent};
+    const d2 t = uv ? d2{uv[i * 2], uv[i * 2 + 1]} : d2{0., 0.};
+    d3 att = mk3(0, 0, 0), wi = mk3(0, 0, 0);
+    const bool ok = mat_scatter<PRT_FEAT_ALL>(S, S.materials[material], ld3(rd + i * 3), f, t, rng, att, wi);
+    ok_out[i] = ok ? 1 : 0;
+    wi_out[i * 3] = ok ? wi.x : 0.; wi_out[i * 3 + 1] = ok ? wi.y : 0.; wi_out[i * 3 + 2] = ok ? wi.z : 0.;
+    att_out[i * 3] = ok ? att.x : 0.; att_out[i * 3 + 1] = ok ? att.y : 0.; att_out[i * 3 + 2] = ok ? att.z : 0.;
+}
+__global__ void k_texture_value(DScene S, int texture, const double* __restrict__ uv, size_t n, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const d3 c = tex_value(S, texture, uv[i * 2], uv[i * 2 + 1]);
+    out[i * 3] = c.x; out[i * 3 + 1] = c.y; out[i * 3 + 2] = c.z;
+}
+
 // Camera::WriteColorAttachment's per-pixel transform (Camera.cpp:279-301): NaN -> 0, LinearToSRGB
 // (:214-221), clamp to [0, 0.9999], * 255 truncated to uint8.
 __global__ void k_tonemap(const float* __restrict__ in, size_t n, uint8_t* __restrict__ out) {
@@ -670,6 +704,23 @@ void launch_sample_lights(const DScene& S, const double* d_origins, size_t n, ui
                           hipStream_t st) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_sample_lights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, d_origins, n, seed, d_out);
+}
+
+void launch_material_eval(const DScene& S, int material, const double* wi, const double* wo, const double* uv, size_t n,
+                          uint64_t seed, double* out, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_material_eval, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, material, wi, wo, uv, n, seed, out);
+}
+void launch_material_scatter(const DScene& S, int material, const double* rd, const double* normal, const double* tangent,
+                             const double* uv, size_t n, uint64_t seed, double* wi_out, double* att_out, int32_t* ok_out,
+                             hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_material_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, material, rd,
+                       d3{normal[0], normal[1], normal[2]}, d3{tangent[0], tangent[1], tangent[2]}, uv, n, seed, wi_out, att_out, ok_out);
+}
+void launch_texture_value(const DScene& S, int texture, const double* uv, size_t n, double* out, hipStream_t st) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_texture_value, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, texture, uv, n, out);
 }
 
 void launch_tonemap(const float* d_in, size_t n, uint8_t* d_out, hipStream_t st) {

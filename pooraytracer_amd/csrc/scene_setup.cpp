@@ -250,8 +250,13 @@ void build_light_tree(const PrtSceneDesc& d, const std::vector<HostTri>& tris, c
     out.area = 0.0;
     RefBuilder rb(tris);
     std::vector<Obj> lights;
-    for (uint32_t m = 0; m < d.n_meshes; ++m) {
-        if (!mats[d.mesh_material[m]].has_emission) continue;
+    // the lights list: what the caller handed to Camera::Render, or what main.cpp:40-45 builds (every emissive mesh)
+    std::vector<uint32_t> list;
+    if (d.light_meshes) list.assign(d.light_meshes, d.light_meshes + d.n_light_meshes);
+    else
+        for (uint32_t m = 0; m < d.n_meshes; ++m)
+            if (mats[d.mesh_material[m]].has_emission) list.push_back(m);
+    for (uint32_t m : list) {
         std::vector<Obj> objs;
         for (uint64_t t = d.mesh_first_tri[m]; t < d.mesh_first_tri[m + 1]; ++t) objs.push_back(Obj{(int32_t)t, -1});
         if (objs.empty()) continue;

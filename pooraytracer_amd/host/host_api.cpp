@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
@@ -53,6 +54,35 @@ struct Hittable::DeviceCache {
         int device = -1;
     };
     std::vector<Replica> replicas;
+    // The `lights` list the scene was created with, as mesh indices (explicitLights false = main.cpp's default list).
+    bool explicitLights = false;
+    std::vector<int32_t> lightMeshes;
+    bool flattened = false;
+    void FlattenOnce(const Hittable& h) {
+        if (flattened) return;
+        h.Flatten(flat);
+        flat.EndMesh();
+        flattened = true;
+    }
+    void DescribeWithLights(PrtSceneDesc& d, unsigned flags) {
+        flat.Describe(d);
+        d.flags = flags;
+        static const int32_t none = 0;
+        d.light_meshes = explicitLights ? (lightMeshes.empty() ? &none : lightMeshes.data()) : nullptr;
+        d.n_light_meshes = explicitLights ? (uint32_t)lightMeshes.size() : 0u;
+    }
+    // A different lights list needs a different light tree: the scenes are re-created (the traversal BVH with them).
+    void SetLights(bool isExplicit, const std::vector<int32_t>& list) {
+        if (isExplicit == explicitLights && list == lightMeshes) return;
+        explicitLights = isExplicit;
+        lightMeshes = list;
+        if (scene) prt_scene_destroy(scene);
+        scene = nullptr;
+        device = -1;
+        for (Replica& r : replicas)
+            if (r.scene) prt_scene_destroy(r.scene);
+        replicas.clear();
+    }
     void EnsureReplicas(const std::vector<int>& devs, unsigned flags) { // devs[0] is served by `scene`
         while (replicas.size() + 1 > devs.size()) {
             if (replicas.back().scene) prt_scene_destroy(replicas.back().scene);
@@ -63,8 +93,7 @@ struct Hittable::DeviceCache {
             Replica& r = replicas[i];
             if (!r.scene) {
                 PrtSceneDesc d;
-                flat.Describe(d);
-                d.flags = flags;
+                DescribeWithLights(d, flags);
                 check(prt_scene_create(&d, &r.scene), "prt_scene_create");
             }
             if (r.device != devs[i + 1]) {
@@ -75,11 +104,9 @@ struct Hittable::DeviceCache {
     }
     void Ensure(const Hittable& h, int dev, unsigned flags = 0) {
         if (!scene) {
-            h.Flatten(flat);
-            flat.EndMesh();
+            FlattenOnce(h);
             PrtSceneDesc d;
-            flat.Describe(d);
-            d.flags = flags;
+            DescribeWithLights(d, flags);
             check(prt_scene_create(&d, &scene), "prt_scene_create");
         }
         if (device != dev) {
@@ -306,20 +333,36 @@ void Camera::Render(Hittable& world, Hittable& lights) {
     Hittable::DeviceCache& dc = world.Device();
     const unsigned sceneFlags = bBuildBvhOnDevice ? PRT_SCENE_DEVICE_BVH : 0u;
     const std::vector<int> devs = devices.empty() ? std::vector<int>{device} : devices;
-    dc.Ensure(world, devs[0], sceneFlags);
-    dc.EnsureReplicas(devs, sceneFlags);
-    // The library derives the NEE light set from the emissive meshes of `world` in mesh order, exactly
-    // as main.cpp:36-45 builds `lights`; a caller-supplied list that disagrees is reported, not used.
+    // `lights` is honoured as given (Camera.cpp:137-139 samples whatever list the caller passes): it is expressed as
+    // the list of world meshes it is made of, in its own order.  The list main.cpp:36-45 builds — every emissive mesh,
+    // in mesh order — is the library's default and needs nothing extra.  A lights list holding geometry that is not a
+    // whole mesh of `world` cannot be expressed through the scene description and is refused, not silently replaced.
+    dc.FlattenOnce(world);
     {
         SceneFlattener lf;
         lights.Flatten(lf);
         lf.EndMesh();
-        uint64_t n = 0;
-        check(prt_scene_light_count(dc.scene, &n), "prt_scene_light_count");
-        if (bSampleLights && n != lf.triangles.size())
-            std::fprintf(stderr, "[pooraytracer] warning: lights holds %zu triangles but world has %llu emissive ones; "
-                                 "using the emissive meshes of world\n", lf.triangles.size(), (unsigned long long)n);
+        std::map<const Triangle*, int32_t> meshOf;
+        for (size_t m = 0; m + 1 < dc.flat.meshFirstTri.size(); ++m)
+            for (uint64_t t = dc.flat.meshFirstTri[m]; t < dc.flat.meshFirstTri[m + 1]; ++t) meshOf[dc.flat.triangles[t]] = (int32_t)m;
+        std::vector<int32_t> list, dflt;
+        for (size_t j = 0; j + 1 < lf.meshFirstTri.size(); ++j) {
+            const uint64_t a = lf.meshFirstTri[j], b = lf.meshFirstTri[j + 1];
+            if (a == b) continue;
+            const auto it = meshOf.find(lf.triangles[a]);
+            const int32_t m = it == meshOf.end() ? -1 : it->second;
+            bool whole = m >= 0 && (b - a) == (dc.flat.meshFirstTri[m + 1] - dc.flat.meshFirstTri[m]);
+            for (uint64_t t = a; t < b && whole; ++t) whole = dc.flat.triangles[dc.flat.meshFirstTri[m] + (t - a)] == lf.triangles[t];
+            if (!whole) throw std::invalid_argument("Camera::Render: `lights` must be made of whole meshes of `world` (mesh '" + lf.meshNames[j] + "' is not)");
+            list.push_back(m);
+        }
+        for (size_t m = 0; m < dc.flat.meshMaterial.size(); ++m)
+            if (dc.flat.materials[dc.flat.meshMaterial[m]]->HasEmission() && dc.flat.meshFirstTri[m + 1] > dc.flat.meshFirstTri[m]) dflt.push_back((int32_t)m);
+        if (list == dflt) dc.SetLights(false, {});
+        else dc.SetLights(true, list);
     }
+    dc.Ensure(world, devs[0], sceneFlags);
+    dc.EnsureReplicas(devs, sceneFlags);
     PrtCamera c;
     c.width = imageWidth; c.height = imageHeight; c.fovy = fovy;
     c.eye[0] = eye.x; c.eye[1] = eye.y; c.eye[2] = eye.z;

@@ -57,6 +57,7 @@ class SceneData:
     materials: List[Material]
     camera: Camera
     textures: List[np.ndarray] = field(default_factory=list)
+    light_meshes: Optional[List[int]] = None  # explicit `lights` list (mesh indices); None = every emissive mesh (main.cpp:40-45)
 
     @property
     def n_tris(self):

@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -132,3 +133,28 @@ def test_cpp_driver_fails_loudly_without_gpu(tmp_path):
     r = subprocess.run([build.MAIN_EXE, res, data.name, "1", "1", str(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode != 0
     assert "no HIP device" in r.stderr or "prt_scene_upload" in r.stderr
+
+
+def test_cmake_build_produces_the_same_libraries(tmp_path):
+    """north_star: "host code stays C++ (CMake)" (reference CMakeLists.txt:13-35).  CMakeLists.txt configures without
+    a GPU (gfx950 cross-compile) and builds libprt_hip, the C++ host library, both drivers and the oracle; the
+    resulting libprt_hip.so exports every symbol include/prt.h declares and reports the header's ABI version."""
+    import ctypes
+    import shutil
+    import subprocess
+    if not (shutil.which("cmake") and shutil.which("ninja")):
+        pytest.skip("cmake / ninja not installed")
+    bdir = str(tmp_path / "build")
+    subprocess.check_call(["cmake", "-S", ROOT, "-B", bdir, "-G", "Ninja"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["cmake", "--build", bdir, "-j", "6"], stdout=subprocess.DEVNULL)
+    for f in ("libprt_hip.so", "libpooraytracer_host.so", "libprt_oracle.so", "render_scene", "pooraytracer_main"):
+        assert os.path.exists(os.path.join(bdir, f)), f
+    nm = subprocess.run(["nm", "-D", "--defined-only", os.path.join(bdir, "libprt_hip.so")], capture_output=True, text=True).stdout
+    exported = {line.split()[-1] for line in nm.splitlines() if line.strip()}
+    assert not [s for s in _abi.EXPORTS if s not in exported]
+    # the version is read in a child process: this one may already hold the in-tree library (and torch's HIP runtime)
+    code = f"import ctypes; print(ctypes.CDLL({os.path.join(bdir, 'libprt_hip.so')!r}).prt_abi_version())"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and int(out.stdout.strip()) == _abi.PRT_ABI_VERSION, out.stderr
+    ldd = subprocess.run(["ldd", os.path.join(bdir, "render_scene")], capture_output=True, text=True).stdout
+    assert "libpooraytracer_host.so" in ldd and "libprt_hip.so" in ldd

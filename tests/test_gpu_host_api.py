@@ -110,9 +110,14 @@ def test_obj_mtl_xml_loader_main_flow(gpu, tmp_path, scene_fn):
     assert r.returncode == 0, r.stderr + r.stdout
     cam = data.camera
     img = np.fromfile(out, dtype=np.float64).reshape(cam.height, cam.width, 3)
-    ref = api.Scene(scenes.apply_loader_uv_fixup(data)).upload(gpu).render(spp=4, max_depth=6, seed=1)
+    fixed = scenes.apply_loader_uv_fixup(data)
+    ref = api.Scene(fixed).upload(gpu).render(spp=4, max_depth=6, seed=1)
     assert np.array_equal(img, ref)
     assert any(f.endswith(".png") for f in os.listdir(tmp_path)) and any(f.endswith(".hdr") for f in os.listdir(tmp_path))
+    # ... and the ORACLE's frame for the loader-normalised scene (the row was tested against itself only)
+    cpu, _ = oracle.Oracle(fixed).render(spp=4, max_depth=6, seed=1)
+    bad = (np.abs(img - cpu) > 1e-9 * np.maximum(1.0, np.abs(cpu))).any(-1)
+    assert bad.mean() <= 1e-3, f"{bad.sum()} pixels differ from the oracle"
 
 
 def test_loader_png_textures_match_ppm(gpu, tmp_path):
@@ -130,3 +135,39 @@ def test_loader_png_textures_match_ppm(gpu, tmp_path):
         assert "Failed" not in r.stderr
         outs.append(np.fromfile(out, dtype=np.float64))
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_camera_render_honours_its_lights_argument(gpu, tmp_path):
+    """Camera::Render(world, lights) samples the list it is GIVEN (Source/Camera.cpp:137-139).  The host API expresses a
+    caller's list as world-mesh indices (PrtSceneDesc.light_meshes); r1 replaced a list that was not main.cpp's with a
+    warning.  A subset, a reordering and main.cpp's own list must each equal the binding and the oracle with the same
+    list; a list holding geometry that is not in world is refused."""
+    build.build_host_example()
+    exe = str(tmp_path / "lights_arg")
+    lib_dir = os.path.dirname(build.HOST_LIB)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(os.path.dirname(lib_dir), "include"),
+                           os.path.join(os.path.dirname(lib_dir), "tests", "cpp", "lights_arg.cpp"), "-L", lib_dir,
+                           "-Wl,-rpath," + lib_dir, "-lpooraytracer_host", "-lprt_hip", "-o", exe])
+    data = scenes.veach_mis(64, 36, light_subdiv=1, plate_cells=2)   # five emissive meshes
+    res = str(tmp_path / "res")
+    scenes.export_obj(data, res)
+    fixed = scenes.apply_loader_uv_fixup(data)
+    emissive = [i for i, m in enumerate(fixed.mesh_material) if fixed.materials[int(m)].type == 4]
+    assert len(emissive) == 5
+    cam = data.camera
+    frames = {}
+    for mode, lm in (("all", None), ("first", emissive[:1]), ("reversed", emissive[::-1])):
+        out = str(tmp_path / f"{mode}.f64")
+        r = subprocess.run([exe, res, data.name, mode, "6", "5", out], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        img = np.fromfile(out, dtype=np.float64).reshape(cam.height, cam.width, 3)
+        import dataclasses
+        sd = dataclasses.replace(fixed, light_meshes=lm)
+        assert np.array_equal(img, api.Scene(sd).upload(gpu).render(spp=6, max_depth=5, seed=1)), mode
+        cpu, _ = oracle.Oracle(sd).render(spp=6, max_depth=5, seed=1)
+        bad = (np.abs(img - cpu) > 1e-9 * np.maximum(1.0, np.abs(cpu))).any(-1)
+        assert bad.mean() <= 1e-3, (mode, int(bad.sum()))
+        frames[mode] = img
+    assert not np.array_equal(frames["all"], frames["first"]) and not np.array_equal(frames["all"], frames["reversed"])
+    r = subprocess.run([exe, res, data.name, "foreign", "1", "1", str(tmp_path / "x.f64")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "must be made of whole meshes" in r.stdout

@@ -110,3 +110,74 @@ def test_jpeg_reader_rejects_garbage(png_check, tmp_path):
     q = tmp_path / "junk.jpg"
     q.write_bytes(b"\xff\xd8\xff\xe0 definitely not a jpeg")
     assert subprocess.run([png_check, str(q)], capture_output=True).returncode != 0
+
+
+# ---------------------------------------------------------------------------------- OBJ / MTL / XML loader behaviour
+@pytest.fixture(scope="module")
+def model_dump(tmp_path_factory):
+    build.build_host_example()
+    exe = str(tmp_path_factory.mktemp("model") / "model_dump")
+    lib_dir = os.path.dirname(build.HOST_LIB)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "model_dump.cpp"),
+                           "-L", lib_dir, "-Wl,-rpath," + lib_dir, "-lpooraytracer_host", "-lprt_hip", "-o", exe])
+    return exe
+
+
+def _write_scene(d, name, obj, mtl, xml):
+    os.makedirs(d / name, exist_ok=True)
+    (d / name / f"{name}.obj").write_text(obj)
+    (d / name / f"{name}.mtl").write_text(mtl)
+    (d / name / f"{name}.xml").write_text(xml)
+    return str(d / name)
+
+
+CAM_XML = ('<?xml version="1.0"?>\n<camera type="perspective" width="16" height="16" fovy="40">\n<eye x="0" y="0" z="5"/>'
+           '<lookat x="0" y="0" z="0"/><up x="0" y="1" z="0"/></camera>\n')
+
+
+def test_loader_triangulates_polygons_as_a_fan(model_dump, tmp_path):
+    """The reference parses with tinyobjloader's default reader configuration (Source/Model.cpp:62-66: triangulate
+    defaults to true), so `Model` never sees a face with more than three vertices and its `fv != 3` guard
+    (Model.cpp:138-141) is not reached; this loader does the triangulation itself, as a fan around the first vertex
+    (v0 v1 v2, v0 v2 v3, ...), and keeps triangles untouched.  Documented in INTEGRATION.md."""
+    obj = ("mtllib poly.mtl\ng quad\nusemtl DiffuseWhite\n"
+           "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 2 0 1\nv 3 0 1\nv 3.5 1 1\nv 2.5 2 1\nv 1.5 1 1\n"
+           "vt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\n"
+           "f 1/1 2/2 3/3 4/4\n"          # quad
+           "g penta\nusemtl DiffuseWhite\n"
+           "f 5 6 7 8 9\n"                # pentagon, no texture coordinates
+           "f -5 -4 -3\n")                # relative indices: the triangle (5, 6, 7)
+    mtl = "newmtl DiffuseWhite\nKd 0.5 0.5 0.5\n"
+    d = _write_scene(tmp_path, "poly", obj, mtl, CAM_XML)
+    r = subprocess.run([model_dump, d, "poly"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.splitlines()
+    meshes = [x for x in lines if x.startswith("mesh")]
+    assert [m.split()[1] for m in meshes] == ["quad", "penta"] and meshes[0].endswith("tris 2") and meshes[1].endswith("tris 4")
+    tris = np.array([[float(v) for v in x.split()[1:]] for x in lines if x.startswith("t ")])
+    V = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [2, 0, 1], [3, 0, 1], [3.5, 1, 1], [2.5, 2, 1], [1.5, 1, 1]], dtype=float)
+    want = [(0, 1, 2), (0, 2, 3), (4, 5, 6), (4, 6, 7), (4, 7, 8), (4, 5, 6)]
+    assert np.array_equal(tris[:, :9].reshape(-1, 3, 3), np.array([[V[i] for i in w] for w in want]))
+    # texture coordinates follow their vertices through the fan; faces without them get the degenerate-UV fix-up (Model.cpp:170-175)
+    assert np.array_equal(tris[0, 9:], [0, 0, 1, 0, 1, 1]) and np.array_equal(tris[1, 9:], [0, 0, 1, 1, 0, 1])
+    assert np.array_equal(tris[2, 9:], [0, 0, 1, 0, 1, 1])
+
+
+def test_loader_light_without_radiance_throws_like_the_reference(model_dump, tmp_path):
+    """`lightRadianceMap.at(mtlname)` (Source/Model.cpp:294): a material whose NAME makes it a DiffuseLight
+    (light1..4 / Light, Model.cpp:16-51) but that has no <light mtlname=...> entry in the XML makes the reference
+    throw std::out_of_range out of the Model constructor; so does this loader.  Unknown names become Lambertian."""
+    obj = "mtllib l.mtl\ng a\nusemtl light2\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\ng b\nusemtl SomethingElse\nf 1 2 3\n"
+    mtl = "newmtl light2\nKd 0 0 0\nnewmtl SomethingElse\nKd 0.2 0.3 0.4\n"
+    d = _write_scene(tmp_path, "l", obj, mtl, CAM_XML)   # no <light> element at all
+    r = subprocess.run([model_dump, d, "l"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and r.stdout.startswith("refused:"), r.stdout
+    d = _write_scene(tmp_path, "l", obj, mtl, CAM_XML + '<light mtlname="light2" radiance="3,2,1"/>\n')
+    r = subprocess.run([model_dump, d, "l"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout
+    meshes = [x for x in r.stdout.splitlines() if x.startswith("mesh")]
+    assert "emission 1" in meshes[0] and "emission 0 skipNEE 0" in meshes[1]
+    # a radiance for a name that is not in the light table is ignored, and a light in the table but with another
+    # material's radiance only still throws
+    d = _write_scene(tmp_path, "l", obj, mtl, CAM_XML + '<light mtlname="SomethingElse" radiance="3,2,1"/>\n')
+    assert subprocess.run([model_dump, d, "l"], capture_output=True, text=True, timeout=60).returncode == 1

@@ -238,3 +238,27 @@ def test_direct_lighting_matches_the_area_integral():
         s = o.render_samples([(i, j)], spp=spp, max_depth=0, seed=5)[0]
         mean, sem = s.mean(0), s.std(0) / np.sqrt(spp)
         assert np.all(np.abs(mean - expect) < 4 * sem + 2e-3 * expect), (mean, expect, sem)
+
+
+def test_explicit_lights_list_changes_only_the_light_selection():
+    """OrcSceneDesc.light_meshes = the `lights` argument of Camera::Render (Camera.cpp:137-139 samples the list it is
+    given).  With only one of two emitters in the list, NEE must pick points on that emitter only and with pdf
+    1 / its area; the default (NULL) is main.cpp:40-45's list of every emissive mesh, in mesh order."""
+    import dataclasses
+    b = scenes._Builder("two-lights")
+    white = b.material(scenes.Material("DiffuseWhite", 0, kd=(0.5, 0.5, 0.5)))
+    l1 = b.material(scenes.Material("light1", 4, emission=(3, 3, 3)))
+    l2 = b.material(scenes.Material("light2", 4, emission=(1, 2, 3)))
+    b.mesh("floor", white, *scenes.quad((-2, 0, -2), (2, 0, -2), (2, 0, 2), (-2, 0, 2)))
+    b.mesh("a", l1, *scenes.quad((-1, 2, -1), (0, 2, -1), (0, 2, 0), (-1, 2, 0)))          # area 1
+    b.mesh("b", l2, *scenes.quad((0.5, 2, 0.5), (2.5, 2, 0.5), (2.5, 2, 2.5), (0.5, 2, 2.5)))  # area 4
+    data = b.build(scenes.Camera(8, 8, 40.0, eye=(0, 1, 6), look_at=(0, 1, 0)))
+    org = np.zeros((4000, 3))
+    both = oracle.Oracle(data).sample_lights(org, seed=5)
+    assert set(np.unique(both["prim"])) == {2, 3, 4, 5} and np.allclose(both["pdf"], 1 / 5.0)
+    assert np.array_equal(oracle.Oracle(dataclasses.replace(data, light_meshes=[1, 2])).sample_lights(org, seed=5)["prim"], both["prim"])
+    only_b = oracle.Oracle(dataclasses.replace(data, light_meshes=[2])).sample_lights(org, seed=5)
+    assert set(np.unique(only_b["prim"])) == {4, 5} and np.allclose(only_b["pdf"], 1 / 4.0)
+    assert (only_b["position"][:, 0] >= 0.5).all()
+    assert oracle.Oracle(dataclasses.replace(data, light_meshes=[])).light_order().size == 0
+    assert list(oracle.Oracle(dataclasses.replace(data, light_meshes=[2, 1])).light_order()) != list(oracle.Oracle(data).light_order())
