@@ -168,6 +168,9 @@ def test_camera_render_honours_its_lights_argument(gpu, tmp_path):
         bad = (np.abs(img - cpu) > 1e-9 * np.maximum(1.0, np.abs(cpu))).any(-1)
         assert bad.mean() <= 1e-3, (mode, int(bad.sum()))
         frames[mode] = img
-    assert not np.array_equal(frames["all"], frames["first"]) and not np.array_equal(frames["all"], frames["reversed"])
+    assert not np.array_equal(frames["all"], frames["first"])
+    # the reversed list gives the SAME frame: BVHNode's constructor sorts its list along the longest axis
+    # (BVH.cpp:12-33), and these five emitters have distinct positions along it — as the oracle agreed above
+    assert np.array_equal(frames["all"], frames["reversed"])
     r = subprocess.run([exe, res, data.name, "foreign", "1", "1", str(tmp_path / "x.f64")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "must be made of whole meshes" in r.stdout
