@@ -717,7 +717,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
         int body = P.items_per_chunk < 2 * lanes ? 64 : 128;
         if (const char* e = std::getenv("PRT_TUNE_BODY")) body = std::max(1, std::atoi(e));
         body = std::max(body, (spp + PRT_MAX_CHUNKS / 2 - 1) / (PRT_MAX_CHUNKS / 2)); // very high spp: the body must fit in half the table
-        double var = 3.0;
+        double var = 4.0; // measured optimum with the multi-queue item dealing (3 before it: short items were fetch-bound)
         if (const char* e = std::getenv("PRT_TUNE_VAR")) var = std::max(0.25, std::atof(e));
         double c = ((double)P.items_per_chunk / (double)lanes) / var;
         for (;;) {

@@ -212,12 +212,14 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     DScene S, DCamera C, DRenderParams P, double* __restrict__ partial, DCounters* ctr) {
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
     __shared__ unsigned long long s_pool[PRT_BLOCK / 64][2];
+    __shared__ uint32_t s_qoff[PRT_BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stk = &s_stack[wave][0][lane];
     volatile unsigned long long* pool = s_pool[wave];
     if (lane == 0) {
         pool[0] = 0;
         pool[1] = 0;
+        s_qoff[wave] = 0;
     }
     // light tree in LDS (dynamic allocation sized by the host; see sample_lights)
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -451,6 +453,26 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                         pool[0] = pn + need;
                     }
                 }
+#elif PRT_ITEM_QUEUES > 1
+                // One returning atomic per wave and pass on the wave's current queue (the queue index is wave-uniform,
+                // so the compiler aggregates the lanes that execute it); a queue that hands out an index past the end
+                // is dry for good (its indices only grow) and the lanes that drew a blank move on to the next one.
+                // s_qoff[wave] = queues this wave has seen run dry.
+                {
+                    uint32_t off = __builtin_amdgcn_readfirstlane(s_qoff[wave]);
+                    item = P.n_items;
+                    while (off < (uint32_t)PRT_ITEM_QUEUES) {
+                        const uint32_t q = (blockIdx.x + off) % (uint32_t)PRT_ITEM_QUEUES;
+                        const unsigned long long idx = atomicAdd(&ctr->queue[q * PRT_QUEUE_STRIDE], 1ULL);
+                        const unsigned long long it = ((idx >> 6) * PRT_ITEM_QUEUES + q) * 64ULL + (idx & 63ULL);
+                        if (it < P.n_items) {
+                            item = it;
+                            break;
+                        }
+                        ++off;
+                    }
+                    atomicMax(&s_qoff[wave], off);
+                }
 #else
                 item = atomicAdd(&ctr->next_item, 1ULL); // per-lane fetch (the compiler aggregates lanes of one pass)
 #endif
@@ -651,7 +673,10 @@ int render_permutation(int feat) {
 // Light-tree nodes (16 bytes each) that fit in LDS next to the traversal stacks without costing a resident block:
 // 160 KB per CU, 32.8 KB of stacks per block, 3 blocks (lean / textured) or 2 (Phong / all).
 // Bytes of dynamic LDS a block may use without costing a resident block: 160 KB per CU, 32832 B static per block.
-int render_lds_budget(int feat) { return render_waves(render_permutation(feat)) >= 3 ? 21504 : 48640; }
+int render_lds_budget(int feat) {
+    const int blocks = render_waves(render_permutation(feat)); // 4 waves per block, 4 SIMDs per CU: blocks per CU = waves per SIMD
+    return ((160 * 1024 / blocks - (int)sizeof(uint32_t) * PRT_STACK_DEPTH * PRT_BLOCK - 128) / 512) * 512; // 48640 / 21504 / 7680
+}
 
 typedef void (*RenderKernel)(DScene, DCamera, DRenderParams, double*, DCounters*);
 template <int FEAT>

@@ -152,10 +152,21 @@ struct DRenderParams {
     int32_t chunk_begin[PRT_MAX_CHUNKS + 1]; // chunk c covers samples [chunk_begin[c], chunk_begin[c+1])
 };
 
+// K3 deals its work items from PRT_ITEM_QUEUES counters instead of one: a single address takes ~90 returning
+// atomics per microsecond, which the short items at the end of a launch (and every launch at low spp) exceed.
+// Queue q owns the 64-item blocks b with b % PRT_ITEM_QUEUES == q, in ascending order; a workgroup starts at queue
+// blockIdx % PRT_ITEM_QUEUES and moves on to the next one when its queue runs dry.
+#ifndef PRT_ITEM_QUEUES
+#define PRT_ITEM_QUEUES 16
+#endif
+#define PRT_QUEUE_STRIDE 32 // in 8-byte words: one counter per 256 bytes (different memory channels)
+
 // device-side counters, zeroed before each call
 struct DCounters {
     unsigned long long next_item;
     unsigned long long rays_closest, rays_shadow, node_fetches, tri_tests, samples;
     unsigned long long inner_rounds, leaf_rounds, refills; // COUNT builds: wave-level scheduling statistics
     unsigned long long tri_full; // COUNT builds: triangle tests that fetched the whole 128-byte record
+    unsigned long long pad_[PRT_QUEUE_STRIDE - 10];
+    unsigned long long queue[PRT_ITEM_QUEUES * PRT_QUEUE_STRIDE]; // queue[q * PRT_QUEUE_STRIDE] = next 64-item-block-local index of queue q
 };
