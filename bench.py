@@ -102,11 +102,11 @@ def record_bytes(info):
 def bytes_per_ray(cc, info):
     """Algorithmic bytes per ray, SURVEY.md §8(d) with this build's record sizes and what the kernel really fetches
     (counters of the counting instantiation of the same kernel): ray in (64 B: fp64 o, tmin, d, tmax) + hit out (32 B)
-    + one node record per node visit + 32 B (plane n, D) per triangle test + 96 B (w, v0, e0, e1) per test that
-    passed the plane / interval check and fetched the rest of the 128-byte record."""
+    + one node record per node visit + 32 B (plane n, D) per triangle test + the rest of the record (64 B: the two
+    edge functions A, a0, B, b0) per test that passed the plane / interval check."""
     rays = max(1, cc["rays_closest"] + cc["rays_shadow"])
     npr, tpr, fpr = cc["node_fetches"] / rays, cc["tri_tests"] / rays, cc["tri_full"] / rays
-    return 64.0 + 32.0 + record_bytes(info) * npr + 32.0 * tpr + 96.0 * fpr, npr, tpr, fpr
+    return 64.0 + 32.0 + record_bytes(info) * npr + 32.0 * tpr + (info["tri_bytes"] - 32.0) * fpr, npr, tpr, fpr
 
 
 def load_pmc(workload):

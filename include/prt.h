@@ -179,6 +179,8 @@ typedef struct PrtBvhInfo {
     double sort_ms, tree_ms, split_ms; /* device builder phases: Morton sort / box segment tree / SAH levels */
     uint32_t node_bytes; /* size of one node record in HBM */
     uint32_t width;      /* children per node */
+    uint32_t tri_bytes;  /* payload of one intersection record: 32 (plane: n, D) + the part read after the interval test */
+    uint32_t tri_stride; /* bytes between records in HBM once uploaded (0 before): tri_bytes, or 128 for scenes that stream from HBM */
 } PrtBvhInfo;
 
 typedef struct PrtScene PrtScene;

@@ -84,6 +84,8 @@ class PrtBvhInfo(C.Structure):
         ("split_ms", C.c_double),
         ("node_bytes", C.c_uint32),
         ("width", C.c_uint32),
+        ("tri_bytes", C.c_uint32),
+        ("tri_stride", C.c_uint32),
     ]
 
 

@@ -456,23 +456,24 @@ namespace {
 // out[i] = in[order[i]] for the 128-byte intersection and 96-byte shading records, 16 bytes per lane
 __global__ void k_gather_tris(const uint4* __restrict__ tri_in, const uint4* __restrict__ shade_in,
                               const uint32_t* __restrict__ order, uint32_t n, uint4* __restrict__ tri_out,
-                              uint4* __restrict__ shade_out) {
+                              uint4* __restrict__ shade_out, uint32_t out_pieces) {
+    constexpr uint32_t TP = sizeof(DTri) / 16, SP = sizeof(DTriShade) / 16;
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t i = (uint32_t)(t / 14), c = (uint32_t)(t % 14);
+    const uint32_t i = (uint32_t)(t / (TP + SP)), c = (uint32_t)(t % (TP + SP));
     if (i >= n) return;
     const uint32_t src = order[i];
-    if (c < 8) tri_out[(uint64_t)i * 8 + c] = tri_in[(uint64_t)src * 8 + c];
-    else shade_out[(uint64_t)i * 6 + (c - 8)] = shade_in[(uint64_t)src * 6 + (c - 8)];
+    if (c < TP) tri_out[(uint64_t)i * out_pieces + c] = tri_in[(uint64_t)src * TP + c]; // out records sit out_pieces * 16 bytes apart
+    else shade_out[(uint64_t)i * SP + (c - TP)] = shade_in[(uint64_t)src * SP + (c - TP)];
 }
 } // namespace
 
-void launch_gather_tris(const DTri* tri_in, const DTriShade* shade_in, const uint32_t* order, uint32_t n, DTri* tri_out,
-                        DTriShade* shade_out, hipStream_t st) {
-    static_assert(sizeof(DTri) == 8 * 16 && sizeof(DTriShade) == 6 * 16, "record sizes");
-    const uint64_t items = (uint64_t)n * 14;
+void launch_gather_tris(const DTri* tri_in, const DTriShade* shade_in, const uint32_t* order, uint32_t n, void* tri_out,
+                        uint32_t tri_out_stride, DTriShade* shade_out, hipStream_t st) {
+    static_assert(sizeof(DTri) % 16 == 0 && sizeof(DTriShade) % 16 == 0, "records are moved in 16-byte pieces");
+    const uint64_t items = (uint64_t)n * ((sizeof(DTri) + sizeof(DTriShade)) / 16);
     k_gather_tris<<<(unsigned)((items + 255) / 256), 256, 0, st>>>(
         reinterpret_cast<const uint4*>(tri_in), reinterpret_cast<const uint4*>(shade_in), order, n,
-        reinterpret_cast<uint4*>(tri_out), reinterpret_cast<uint4*>(shade_out));
+        reinterpret_cast<uint4*>(tri_out), reinterpret_cast<uint4*>(shade_out), tri_out_stride / 16);
 }
 
 #define BVH_HIP(call)                                                                   \

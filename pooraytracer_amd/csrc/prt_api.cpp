@@ -34,8 +34,8 @@ void launch_material_scatter(const DScene& S, int material, const double* rd, co
                              const double* uv, size_t n, uint64_t seed, double* wi_out, double* att_out, int32_t* ok_out,
                              hipStream_t st);
 void launch_texture_value(const DScene& S, int texture, const double* uv, size_t n, double* out, hipStream_t st);
-void launch_gather_tris(const DTri* tri_in, const DTriShade* shade_in, const uint32_t* order, uint32_t n, DTri* tri_out,
-                        DTriShade* shade_out, hipStream_t st);
+void launch_gather_tris(const DTri* tri_in, const DTriShade* shade_in, const uint32_t* order, uint32_t n, void* tri_out,
+                        uint32_t tri_out_stride, DTriShade* shade_out, hipStream_t st);
 } // namespace prt
 
 namespace {
@@ -258,6 +258,8 @@ int prt_scene_bvh_info(const PrtScene* s, PrtBvhInfo* out) {
     *out = s->bvh_info;
     out->node_bytes = (uint32_t)sizeof(DNode);
     out->width = PRT_BVH_WIDTH;
+    out->tri_bytes = (uint32_t)sizeof(DTri);
+    out->tri_stride = s->device >= 0 ? s->d.tri_stride : 0u;
     return PRT_OK;
 }
 
@@ -312,10 +314,21 @@ static int upload_impl(PrtScene* s, int device) {
         DTri& a = dt[i];
         std::memcpy(a.n, T.normal, 24);
         a.D = T.D;
+#if PRT_TRI_FORM == 1
+        a.A[0] = T.e1[1] * T.w[2] - T.w[1] * T.e1[2]; // e1 x w
+        a.A[1] = T.e1[2] * T.w[0] - T.w[2] * T.e1[0];
+        a.A[2] = T.e1[0] * T.w[1] - T.w[0] * T.e1[1];
+        a.B[0] = T.w[1] * T.e0[2] - T.e0[1] * T.w[2]; // w x e0
+        a.B[1] = T.w[2] * T.e0[0] - T.e0[2] * T.w[0];
+        a.B[2] = T.w[0] * T.e0[1] - T.e0[0] * T.w[1];
+        a.a0 = T.v[0][0] * a.A[0] + T.v[0][1] * a.A[1] + T.v[0][2] * a.A[2];
+        a.b0 = T.v[0][0] * a.B[0] + T.v[0][1] * a.B[1] + T.v[0][2] * a.B[2];
+#else
         std::memcpy(a.w, T.w, 24);
         std::memcpy(a.v0, T.v[0], 24);
         std::memcpy(a.e0, T.e0, 24);
         std::memcpy(a.e1, T.e1, 24);
+#endif
         DTriShade& b = ds[i];
         std::memset(&b, 0, sizeof(b));
         std::memcpy(b.tangent, T.tangent, 24);
@@ -328,6 +341,20 @@ static int upload_impl(PrtScene* s, int device) {
     DScene& d = s->d;
     std::memset(&d, 0, sizeof(d));
     int rc;
+    // packed records for scenes the caches hold, one record per 128-byte line for scenes that stream from HBM
+    uint32_t stride = (uint64_t)n * sizeof(DTri) > PRT_TRI_PADDED_ABOVE ? 128u : (uint32_t)sizeof(DTri);
+    if (const char* e = std::getenv("PRT_TUNE_TRI_STRIDE")) stride = std::atoi(e) == 128 ? 128u : (uint32_t)sizeof(DTri);
+    if (sizeof(DTri) > 96) stride = (uint32_t)sizeof(DTri);
+    d.tri_stride = stride;
+    auto up_tris = [&](const DTri** out) -> int { // host records (packed) -> device records `stride` bytes apart
+        if (stride == sizeof(DTri)) return s->up(dt, out);
+        void* p = nullptr;
+        PRT_HIP(hipMalloc(&p, std::max<size_t>(n * (size_t)stride, 256)));
+        s->allocs.push_back(p);
+        if (n) PRT_HIP(hipMemcpy2D(p, stride, dt.data(), sizeof(DTri), sizeof(DTri), n, hipMemcpyHostToDevice));
+        *out = static_cast<const DTri*>(p);
+        return PRT_OK;
+    };
     if (s->device_bvh) {
         std::vector<prt::PrimBox> pb;
         prt::prim_boxes(s->tris, pb);
@@ -353,11 +380,11 @@ static int upload_impl(PrtScene* s, int device) {
         if (!rc) rc = s->up(ds, &s_in);
         hipError_t e = hipSuccess;
         if (!rc) {
-            e = hipMalloc(&t_out, n * sizeof(DTri));
+            e = hipMalloc(&t_out, n * (size_t)stride);
             if (e == hipSuccess) { s->allocs.push_back(t_out); e = hipMalloc(&s_out, n * sizeof(DTriShade)); }
             if (e == hipSuccess) {
                 s->allocs.push_back(s_out);
-                prt::launch_gather_tris(t_in, s_in, db.d_order, (uint32_t)n, static_cast<DTri*>(t_out),
+                prt::launch_gather_tris(t_in, s_in, db.d_order, (uint32_t)n, t_out, stride,
                                         static_cast<DTriShade*>(s_out), nullptr);
                 e = hipGetLastError();
                 if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -389,7 +416,7 @@ static int upload_impl(PrtScene* s, int device) {
         s->bvh_info.split_ms = db.ms_split;
     } else {
         if ((rc = s->up(s->bvh.nodes, &d.nodes))) return rc;
-        if ((rc = s->up(dt, &d.tris))) return rc;
+        if ((rc = up_tris(&d.tris))) return rc;
         if ((rc = s->up(ds, &d.shade))) return rc;
     }
     if ((rc = s->up(s->mats, &d.materials))) return rc;

@@ -99,7 +99,16 @@ struct WorkCount {
     uint32_t inner_rounds, leaf_rounds; // COUNT builds: wave-level executions of inner_step / leaf_step (lane 0 counts)
 };
 
-// Triangle::Hit + IsInterior (Triangle.cpp:54-83,100-113): same expressions, inclusive interval.
+// Record i of the intersection array.  PAD: the records sit 128 bytes apart (one per line; scenes that stream from
+// HBM) instead of sizeof(DTri) — a kernel template parameter, so the stride is a constant of each instantiation
+// (as a run-time value it cost the register-starved textured permutation 3 %).
+template <bool PAD>
+PRT_DEV const DTri* tri_at(const DScene& S, uint32_t i) {
+    return reinterpret_cast<const DTri*>(reinterpret_cast<const char*>(S.tris) + (size_t)i * (PAD ? 128u : (uint32_t)sizeof(DTri)));
+}
+
+// Triangle::Hit + IsInterior (Triangle.cpp:54-83,100-113), inclusive interval.  PRT_TRI_FORM 0: the reference's
+// expressions; 1: the same quantities through precomputed edge functions (see DTri).
 PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, double tmin, double tmax, double& t_out, double& a_out,
                       double& b_out, const double4* pre = nullptr, uint32_t* n_full = nullptr) {
     const double4* q = reinterpret_cast<const double4*>(T);
@@ -108,6 +117,22 @@ PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, double tmin, doubl
     double denom = dot(n, d);
     if (fabs(denom) < 1e-8) return false;
     double t = (q0.w - dot(n, o)) / denom;
+#if PRT_TRI_FORM == 1
+    if (!(tmin <= t && t <= tmax)) return false;
+    if (n_full) ++*n_full;
+    {
+        const double4 q2 = q[2];
+        const d3 p = o + d * t;
+        const double alpha = (p.x * q1.x + p.y * q1.y + p.z * q1.z) - q1.w;
+        const double beta = (p.x * q2.x + p.y * q2.y + p.z * q2.z) - q2.w;
+        if (alpha != alpha || beta != beta) return false;
+        if ((alpha < 0) || (beta < 0) || (alpha + beta > 1)) return false;
+        t_out = t;
+        a_out = alpha;
+        b_out = beta;
+        return true;
+    }
+#endif
 #if PRT_TRI_EAGER
     double4 q2 = q[2], q3 = q[3]; // whole record requested up front: one memory latency per test instead of two
     asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w)); // keeps the loads above the branch
@@ -189,6 +214,7 @@ PRT_DEV SlabAxis slab_axis(double o, double d, float B, float g0, float gs) {
 // cull); every accept/reject of a hit is the fp64 triangle test.  `early`: traversal stops as soon as
 // a hit with t < early is accepted (shadow rays: anything that close is an occluder for certain);
 // -inf for closest-hit.  The stack lives in LDS, lane-strided (`stk` = this lane's column, stride 64).
+template <bool PAD>
 struct Trav {
     d3 o, d;
     double tmin, early;
@@ -412,17 +438,17 @@ struct Trav {
         // latency overlaps the current test instead of adding to it (the kernels wait on memory half the time).
         // Measured: bathroom2 +4.4 %, veach-mis +2.3 %, S0 +4.5 %, S4 +5.8 %, cornell unchanged; requesting the
         // next triangle's first 64 bytes instead of 32 costs cornell 7 % (registers) and gains nothing elsewhere.
-        double4 q0n = *reinterpret_cast<const double4*>(S.tris + first);
+        double4 q0n = *reinterpret_cast<const double4*>(tri_at<PAD>(S, first));
 #endif
         for (uint32_t i = 0; i < cnt; ++i) {
             double t, al, be;
             if (COUNT) wc.tris++;
 #if PRT_LEAF_PREFETCH
             const double4 q0c = q0n;
-            if (i + 1 < cnt) q0n = *reinterpret_cast<const double4*>(S.tris + first + i + 1);
-            if (tri_test(S.tris + first + i, o, d, tmin, hit.t, t, al, be, &q0c, COUNT ? &wc.tris_full : nullptr)) {
+            if (i + 1 < cnt) q0n = *reinterpret_cast<const double4*>(tri_at<PAD>(S, first + i + 1));
+            if (tri_test(tri_at<PAD>(S, first + i), o, d, tmin, hit.t, t, al, be, &q0c, COUNT ? &wc.tris_full : nullptr)) {
 #else
-            if (tri_test(S.tris + first + i, o, d, tmin, hit.t, t, al, be, nullptr, COUNT ? &wc.tris_full : nullptr)) {
+            if (tri_test(tri_at<PAD>(S, first + i), o, d, tmin, hit.t, t, al, be, nullptr, COUNT ? &wc.tris_full : nullptr)) {
 #endif
                 hit.t = t;
                 hit.alpha = al;

@@ -88,7 +88,7 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 // Persistent waves; every lane pulls its next ray from a global counter the moment its traversal
 // ends.  The stepping loop is left (and the finished lanes refilled) once no more than
 // PRT_K1_KEEP lanes are still traversing.
-template <bool COUNT>
+template <bool COUNT, bool PAD>
 __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScene S, const PrtRay* __restrict__ rays, size_t n,
                                                              PrtHit* __restrict__ hits, DCounters* ctr) {
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
     uint32_t* stk = &s_stack[wave][0][lane];
     WorkCount wc{0, 0, 0, 0, 0};
     uint32_t nrays = 0;
-    Trav tr;
+    Trav<PAD> tr;
     tr.init(S, mk3(0, 0, 0), mk3(0, 0, 1), 0.0, 0.0, 0.0);
     tr.active = false;
     bool have = false;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
             if (have) {
                 PrtHit out;
                 if (tr.hit.tri >= 0) {
-                    const DTri* T = S.tris + tr.hit.tri;
+                    const DTri* T = tri_at<PAD>(S, (uint32_t)tr.hit.tri);
                     const d3 nrm = mk3(T->n[0], T->n[1], T->n[2]);
                     out.t = tr.hit.t;
                     out.alpha = tr.hit.alpha;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
         }
         if (__ballot(tr.active || have) == 0ULL && exhausted) break;
         do {
-            tr.round<COUNT>(S, stk, wc);
+            tr.template round<COUNT>(S, stk, wc);
         } while (wave_count(tr.active) > PRT_K1_KEEP);
     }
     unsigned long long a = wave_sum((unsigned long long)nrays);
@@ -186,11 +186,11 @@ struct ShadeCtx {
     d2 uv;
     int32_t material;
 };
-template <int FEAT>
+template <int FEAT, bool PAD>
 PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 ro, d3 rd, const HitInfo& h) {
     ShadeCtx c;
     const DTriShade* sh = S.shade + h.tri;
-    const DTri* T = S.tris + h.tri;
+    const DTri* T = tri_at<PAD>(S, (uint32_t)h.tri);
     const d3 gn = mk3(T->n[0], T->n[1], T->n[2]);
     const bool front = dot(rd, gn) < 0.;
     c.f.n = front ? gn : -gn;
@@ -207,7 +207,7 @@ PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 ro, d3 rd, const HitInfo& h) {
     return c;
 }
 
-template <bool COUNT, int FEAT, bool LLDS>
+template <bool COUNT, int FEAT, bool LLDS, bool PAD>
 __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     DScene S, DCamera C, DRenderParams P, double* __restrict__ partial, DCounters* ctr) {
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     Rng rng;
     rng.s = 0;
     const double inv_spp = 1.0 / P.spp; // pixelSamplesScale, Camera.cpp:83
-    Trav tr;
+    Trav<PAD> tr;
     tr.init(S, mk3(0, 0, 0), rd, 0.0, 0.0, 0.0);
     tr.active = false;
 
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                         do_scatter = true;
                         if (P.sample_lights && S.n_lights > 0 && !m.skip_light_sampling) {
                             // next-event estimation, Camera.cpp:137-155: pick the light point now (4 draws)
-                            const d3 gn = ld3(S.tris[h.tri].n);
+                            const d3 gn = ld3(tri_at<PAD>(S, (uint32_t)h.tri)->n);
                             const d3 fn = dot(rd, gn) < 0. ? gn : -gn;
                             const LightPick lp = sample_lights<LLDS>(S, pos, rng, lds_lights, P.light_lds, lds_ltris, P.ltri_lds);
                             double dist;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     sh.alpha = sh_alpha;
                     sh.beta = sh_beta;
                     sh.tri = sh_tri;
-                    const ShadeCtx c = make_ctx<FEAT>(S, to, rd, sh);
+                    const ShadeCtx c = make_ctx<FEAT, PAD>(S, to, rd, sh);
                     const DMaterial& m = MATERIAL(c.material);
                     d3 ln0;
                     double pdf;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     sh.alpha = sh_alpha;
                     sh.beta = sh_beta;
                     sh.tri = sh_tri;
-                    const ShadeCtx c = make_ctx<FEAT>(S, pos, rd, sh);
+                    const ShadeCtx c = make_ctx<FEAT, PAD>(S, pos, rd, sh);
                     const DMaterial& m = MATERIAL(c.material);
                     d3 att, wi;
                     if (mat_scatter<FEAT>(S, m, rd, c.f, c.uv, rng, att, wi, have_fr, fr_seen)) {
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
 
         // ---------------- traversal steps until enough lanes have finished to be worth refilling
         do {
-            tr.round<COUNT>(S, stk, wc, P.leaf_batch, P.inner_min);
+            tr.template round<COUNT>(S, stk, wc, P.leaf_batch, P.inner_min);
         } while (wave_count(tr.active) > P.keep);
     }
 
@@ -679,24 +679,29 @@ int render_lds_budget(int feat) {
 }
 
 typedef void (*RenderKernel)(DScene, DCamera, DRenderParams, double*, DCounters*);
-template <int FEAT>
+template <int FEAT, bool PAD>
 static RenderKernel render_kernel_feat(bool count, bool llds) {
-    if (count) return llds ? k_render<true, FEAT, true> : k_render<true, FEAT, false>;
-    return llds ? k_render<false, FEAT, true> : k_render<false, FEAT, false>;
+    if (count) return llds ? k_render<true, FEAT, true, PAD> : k_render<true, FEAT, false, PAD>;
+    return llds ? k_render<false, FEAT, true, PAD> : k_render<false, FEAT, false, PAD>;
 }
-static RenderKernel render_kernel(bool count, int feat, bool llds) {
+template <bool PAD>
+static RenderKernel render_kernel_pad(bool count, int feat, bool llds) {
     switch (render_permutation(feat)) {
-    case 0: return render_kernel_feat<0>(count, llds);
-    case PRT_FEAT_TEX: return render_kernel_feat<PRT_FEAT_TEX>(count, llds);
-    case PRT_FEAT_PHONG: return render_kernel_feat<PRT_FEAT_PHONG>(count, llds);
-    case PRT_FEAT_CT: return render_kernel_feat<PRT_FEAT_CT>(count, llds);
-    default: return render_kernel_feat<PRT_FEAT_ALL>(count, llds);
+    case 0: return render_kernel_feat<0, PAD>(count, llds);
+    case PRT_FEAT_TEX: return render_kernel_feat<PRT_FEAT_TEX, PAD>(count, llds);
+    case PRT_FEAT_PHONG: return render_kernel_feat<PRT_FEAT_PHONG, PAD>(count, llds);
+    case PRT_FEAT_CT: return render_kernel_feat<PRT_FEAT_CT, PAD>(count, llds);
+    default: return render_kernel_feat<PRT_FEAT_ALL, PAD>(count, llds);
     }
+}
+// `pad`: the scene's intersection records sit 128 bytes apart (DScene::tri_stride)
+static RenderKernel render_kernel(bool count, int feat, bool llds, bool pad) {
+    return pad ? render_kernel_pad<true>(count, feat, llds) : render_kernel_pad<false>(count, feat, llds);
 }
 
 int render_blocks_per_cu(bool count, int feat, size_t dyn_lds) {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel(count, feat, dyn_lds != 0), PRT_BLOCK, dyn_lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel(count, feat, dyn_lds != 0, false), PRT_BLOCK, dyn_lds);
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
@@ -706,8 +711,10 @@ void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hit
     if (n == 0) return;
     size_t want = (n + PRT_BLOCK - 1) / PRT_BLOCK;
     unsigned grid = (unsigned)std::min<size_t>(want, (size_t)n_cu * 5); // 5 x 32 KB LDS stacks per CU
-    if (count) hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(PRT_BLOCK), 0, st, S, d_rays, n, d_hits, d_ctr);
-    else hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(PRT_BLOCK), 0, st, S, d_rays, n, d_hits, d_ctr);
+    const bool pad = S.tri_stride == 128u && sizeof(DTri) != 128;
+    auto k = count ? (pad ? k_trace_closest<true, true> : k_trace_closest<true, false>)
+                   : (pad ? k_trace_closest<false, true> : k_trace_closest<false, false>);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(PRT_BLOCK), 0, st, S, d_rays, n, d_hits, d_ctr);
 }
 
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
@@ -715,7 +722,8 @@ void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, do
     static_assert(sizeof(DMaterial) % 16 == 0, "materials are staged in 16-byte pieces");
     const size_t dyn_lds = (size_t)P.light_lds * sizeof(DLightNode) + (size_t)P.mat_lds * sizeof(DMaterial) +
                            (size_t)P.ltri_lds * sizeof(DLightTri);
-    hipLaunchKernelGGL(render_kernel(count, feat, dyn_lds != 0), dim3(grid), dim3(PRT_BLOCK), dyn_lds, st, S, C, P, d_partial, d_ctr);
+    const bool pad = S.tri_stride == 128u && sizeof(DTri) != 128;
+    hipLaunchKernelGGL(render_kernel(count, feat, dyn_lds != 0, pad), dim3(grid), dim3(PRT_BLOCK), dyn_lds, st, S, C, P, d_partial, d_ctr);
 }
 
 void launch_finalize(const DCamera& C, const DRenderParams& P, const double* d_partial, double* d64, float* d32,

@@ -62,6 +62,26 @@ struct alignas(64) DNode {
 static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
 #endif
 
+#ifndef PRT_TRI_FORM
+#define PRT_TRI_FORM 1 // 1: edge functions on a 96-byte record (measured +2...9 %); 0: the reference's expressions on a 128-byte record
+#endif
+#if PRT_TRI_FORM == 1
+// 96 bytes: the plane (n, D) for the interval test, then IsInterior as two edge functions.  With w = n/(n.n):
+//   alpha = w . ((p - v0) x e1) = (p - v0) . (e1 x w) = p . A - a0,   A = e1 x w, a0 = v0 . A
+//   beta  = w . (e0 x (p - v0)) = (p - v0) . (w x e0) = p . B - b0,   B = w x e0, b0 = v0 . B
+// (scalar triple product identities of Triangle.cpp:104-107; same values up to rounding, 4 loads and 8 fp64
+// operations instead of 6 loads and 24).
+// In HBM the records sit DScene::tri_stride bytes apart: 96 (packed) for scenes the caches hold, 128 (one record per
+// 128-byte line, none straddling two) for scenes that stream from HBM — measured: packed +3 % on the cornell frame,
+// padded +6 % on the 8M-triangle soup.
+struct alignas(32) DTri {
+    double n[3];   // unit geometric normal        (Triangle.cpp:19)
+    double D;      // dot(normal, v0)              (Triangle.cpp:50)
+    double A[3], a0;
+    double B[3], b0;
+};
+static_assert(sizeof(DTri) == 96, "DTri must be 96 bytes");
+#else
 struct alignas(128) DTri {
     double n[3];   // unit geometric normal        (Triangle.cpp:19)
     double D;      // dot(normal, v0)              (Triangle.cpp:50)
@@ -71,6 +91,7 @@ struct alignas(128) DTri {
     double e1[3];  // v2 - v0
 };
 static_assert(sizeof(DTri) == 128, "DTri must be 128 bytes");
+#endif
 
 struct alignas(32) DTriShade {
     double tangent[3]; // Triangle.cpp:31-46
@@ -129,7 +150,10 @@ struct DScene {
     float pad_;
     float grid_origin[3]; // PRT_NODE16: box coordinate = grid_origin + q * grid_step
     float grid_step[3];
+    uint32_t tri_stride;  // bytes between consecutive DTri records (sizeof(DTri), or 128 for HBM-resident scenes)
+    uint32_t pad2_;
 };
+#define PRT_TRI_PADDED_ABOVE (256ull << 20) // triangle bytes beyond which records are padded to 128 bytes (Infinity Cache size)
 
 // camera state after Camera::Initialize (Camera.cpp:75-106), computed on the host
 struct DCamera {
