@@ -84,12 +84,19 @@ struct Rng {
     void seed(uint64_t seed, uint64_t pixel, uint64_t sample) {
         s = mix64(seed + 0x9E3779B97F4A7C15ULL * (pixel + 1));
         s = mix64(s ^ (0xD1B54A32D192ED03ULL * (sample + 1)));
+        if (s == 0) s = 0x9E3779B97F4A7C15ULL; // the all-zero state is the generator's fixed point
     }
-    // RandomDouble(), RandomNumberGenerator.h:16-19: rand() / (RAND_MAX + 1.0), RAND_MAX = 2^31-1
+    // RandomDouble(), RandomNumberGenerator.h:16-19: rand() / (RAND_MAX + 1.0), RAND_MAX = 2^31-1.
+    // The stream of one (seed, pixel, sample) key is xoroshiro64* (Blackman & Vigna) started from the hashed key:
+    // one 32-bit multiply per number; its top 31 bits are used (the low bits are the generator's weak ones).
     double next() {
-        s += 0x9E3779B97F4A7C15ULL;
-        uint64_t r = mix64(s) >> 33; // 31 bits
-        return (double)r / 2147483648.0;
+        uint32_t s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+        const uint32_t r = s0 * 0x9E3779BBu;
+        s1 ^= s0;
+        s0 = ((s0 << 26) | (s0 >> 6)) ^ s1 ^ (s1 << 9);
+        s1 = (s1 << 13) | (s1 >> 19);
+        s = ((uint64_t)s1 << 32) | s0;
+        return (double)(r >> 1) / 2147483648.0;
     }
 };
 thread_local Rng g_rng;

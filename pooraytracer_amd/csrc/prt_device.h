@@ -64,7 +64,8 @@ PRT_DEV d3 normalize_len(d3 v, double& len) {
 
 // ------------------------------------------------------------------ keyed counter RNG
 // Replaces the reference's global std::rand() (RandomNumberGenerator.h:16-19) by a stream keyed on
-// (seed, pixel, sample); each draw yields 31 bits so xi = r / 2^31 has rand()'s granularity.
+// (seed, pixel, sample): the key is hashed (two splitmix64 finalisers) into the state of a xoroshiro64* generator;
+// each draw yields 31 bits so xi = r / 2^31 has rand()'s granularity.
 PRT_DEV uint64_t mix64(uint64_t z) {
     z ^= z >> 30;
     z *= 0xBF58476D1CE4E5B9ULL;
@@ -78,11 +79,19 @@ struct Rng {
     PRT_DEV void seed(uint64_t seed, uint64_t pixel, uint64_t sample) {
         s = mix64(seed + 0x9E3779B97F4A7C15ULL * (pixel + 1));
         s = mix64(s ^ (0xD1B54A32D192ED03ULL * (sample + 1)));
+        if (s == 0) s = 0x9E3779B97F4A7C15ULL; // the all-zero state is the generator's fixed point
     }
+    // xoroshiro64* started from the hashed key, top 31 bits: one quarter-rate 32-bit multiply per number instead of the
+    // two 64-bit multiplies (eight quarter-rate instructions) of a splitmix hash per number — with the kernels VALU-bound
+    // the cheaper stream is worth +4 % (measured against a trivial LCG: +5 %).  Same stream in oracle/pt_oracle.cpp.
     PRT_DEV double next() {
-        s += 0x9E3779B97F4A7C15ULL;
-        uint32_t r = (uint32_t)(mix64(s) >> 33);
-        return (double)r * (1.0 / 2147483648.0);
+        uint32_t s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
+        const uint32_t r = s0 * 0x9E3779BBu;
+        s1 ^= s0;
+        s0 = __builtin_amdgcn_alignbit(s0, s0, 6) ^ s1 ^ (s1 << 9); // rotl(s0, 26)
+        s1 = __builtin_amdgcn_alignbit(s1, s1, 19);                 // rotl(s1, 13)
+        s = ((uint64_t)s1 << 32) | s0;
+        return (double)(r >> 1) * (1.0 / 2147483648.0);
     }
 };
 

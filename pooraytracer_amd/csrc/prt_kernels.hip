@@ -361,14 +361,16 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     const d3 emission = ld3(MATERIAL(lmat).emission);
                     const d3 wo = world_to_local(-rd, c.f);
                     const d3 lwi = world_to_local(td, c.f);
-                    const d3 lln = world_to_local(ln, c.f);
                     const d3 fr = mat_eval<FEAT>(S, m, lwi, wo, c.uv, rng);
                     if (FEAT & PRT_FEAT_TEX) {
                         have_fr = m.type == 0; // Lambertian: Eval returned albedo / pi, which Scatter needs again
                         fr_seen = fr;
                     }
                     const double cosT = lwi.z;
-                    const double cosTB = dot(lln, -lwi);
+                    // cosThetaB = dot(WorldToLocal(lightNormal), -wi) (Camera.cpp:166-170): the shading frame is
+                    // orthonormal (tangent in the triangle's plane, bitangent = t x n), so the local dot product IS the
+                    // world one — three multiplies instead of a third change of basis; differs by rounding only
+                    const double cosTB = -dot(ln, td);
                     // Camera.cpp:172: emission*fr*cosT*cosTB/dist^2/pdf, the scalar factor folded into one division
                     const d3 direct = (emission * fr) * (cosT * cosTB / ((dist * dist) * pdf));
                     ADD_RADIANCE(direct);
