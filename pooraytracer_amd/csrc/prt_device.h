@@ -77,8 +77,8 @@ PRT_DEV uint64_t mix64(uint64_t z) {
 struct Rng {
     uint64_t s;
     PRT_DEV void seed(uint64_t seed, uint64_t pixel, uint64_t sample) {
-        s = mix64(seed + 0x9E3779B97F4A7C15ULL * (pixel + 1));
-        s = mix64(s ^ (0xD1B54A32D192ED03ULL * (sample + 1)));
+        // one finaliser over the whole key (Stafford's mix13 avalanches every input bit): pixel and sample are below 2^32
+        s = mix64((seed + 0x9E3779B97F4A7C15ULL) ^ ((pixel + 1) << 32) ^ (sample + 1));
         if (s == 0) s = 0x9E3779B97F4A7C15ULL; // the all-zero state is the generator's fixed point
     }
     // xoroshiro64* started from the hashed key, top 31 bits: one quarter-rate 32-bit multiply per number instead of the
