@@ -691,9 +691,10 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.rr = p->russian_roulette;
     P.inv_rr = 1.0 / p->russian_roulette;
     // wave scheduling thresholds (developer overrides through the environment for sweeps)
-    P.keep = s->feat == 0 ? 24 : s->feat == 2 ? 20 : 16; // measured optima at the BASELINE spp (lean 24, Phong 20, textured / all 16)
-    P.leaf_batch = 32;
-    P.inner_min = 12;
+    // measured optima at the BASELINE spp with 4-wide nodes (flat within 2 %): lean 24 / 48 / 16, textured 20 / 40 / 12, others 20 / 32 / 12
+    P.keep = s->feat == 0 ? 24 : 20;
+    P.leaf_batch = s->feat == 0 ? 48 : s->feat == 1 ? 40 : 32;
+    P.inner_min = s->feat == 0 ? 16 : 12;
     if (const char* e = std::getenv("PRT_TUNE_KEEP")) P.keep = std::atoi(e);
     if (const char* e = std::getenv("PRT_TUNE_LEAF_BATCH")) P.leaf_batch = std::atoi(e);
     if (const char* e = std::getenv("PRT_TUNE_INNER_MIN")) P.inner_min = std::atoi(e);

@@ -47,12 +47,57 @@ PRT_DEV d3 operator*(double s, d3 a) { return {s * a.x, s * a.y, s * a.z}; }
 PRT_DEV d3 operator/(d3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
 PRT_DEV double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PRT_DEV d3 cross(d3 x, d3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
-PRT_DEV double length(d3 v) { return sqrt(dot(v, v)); }
-PRT_DEV d3 normalize(d3 v) { return v * (1.0 / sqrt(dot(v, v))); }
-// normalize(v) and length(v) from one sqrt — the same values as glm::normalize / glm::length
+// fp64 square root / reciprocal for the shading code, where the kernels are VALU-bound: the hardware estimate
+// (v_rsq_f64 / v_rcp_f64, ~2^-23 relative) plus one coupled Newton step and one residual correction — within an ulp
+// or two of the IEEE result (the parity tolerance is 1e-9) in 7-8 instructions instead of the 14-17 of the
+// correctly rounded, range-scaled library sequences.  Arguments are positive normal numbers wherever these are
+// used (squared lengths, pdfs, |direction components|); zero is handled, NaN propagates.  PRT_FAST_F64=0: IEEE.
+#ifndef PRT_FAST_F64
+#define PRT_FAST_F64 1
+#endif
+#if PRT_FAST_F64
+PRT_DEV double fast_rsqrt(double x) { // 1 / sqrt(x), x > 0
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    const double h1 = fma(h, r, h), g1 = fma(g, r, g); // h1 ~ 0.5 / sqrt(x), g1 ~ sqrt(x)
+    const double e = fma(-h1, g1, 0.5);
+    return 2.0 * fma(h1, e, h1);
+}
+PRT_DEV double fast_sqrt(double x) { // sqrt(x), x >= 0
+    const double y = __builtin_amdgcn_rsq(x);
+    const double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    const double g1 = fma(g, r, g), h1 = fma(h, r, h);
+    const double d = fma(-g1, g1, x);
+    const double s = fma(d, h1, g1);
+    return x == 0.0 ? 0.0 : s;
+}
+PRT_DEV double fast_rcp(double b) { // 1 / b, b != 0
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return r;
+}
+PRT_DEV double fast_div(double a, double b) { // a / b, b != 0
+    const double r = fast_rcp(b);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+#else
+PRT_DEV double fast_rsqrt(double x) { return 1.0 / sqrt(x); }
+PRT_DEV double fast_sqrt(double x) { return sqrt(x); }
+PRT_DEV double fast_rcp(double b) { return 1.0 / b; }
+PRT_DEV double fast_div(double a, double b) { return a / b; }
+#endif
+PRT_DEV double length(d3 v) { return fast_sqrt(dot(v, v)); }
+PRT_DEV d3 normalize(d3 v) { return v * fast_rsqrt(dot(v, v)); } // glm::normalize = v * inversesqrt(dot(v, v))
+// normalize(v) and length(v) from one square root — glm::normalize / glm::length up to rounding
 PRT_DEV d3 normalize_len(d3 v, double& len) {
-    len = sqrt(dot(v, v));
-    return v * (1.0 / len);
+    const double q = dot(v, v);
+    const double inv = fast_rsqrt(q);
+    len = q * inv;
+    return v * inv;
 }
 
 #define PRT_PI 3.14159265358979323846
@@ -571,10 +616,10 @@ PRT_DEV d2 disk_concentric(d2 u) {
     // RandomNumberGenerator.h:39-56: theta = pi/4 * (y/x), or pi/2 - pi/4 * (x/y) — i.e. sin and cos swapped
     double sn, cs;
     if (fabs(off.x) > fabs(off.y)) {
-        sincos_quarter(PRT_PI_OVER_4 * (off.y / off.x), sn, cs);
+        sincos_quarter(PRT_PI_OVER_4 * fast_div(off.y, off.x), sn, cs);
         return {off.x * cs, off.x * sn};
     }
-    sincos_quarter(PRT_PI_OVER_4 * (off.x / off.y), cs, sn); // cos(pi/2 - phi) = sin(phi), sin(pi/2 - phi) = cos(phi)
+    sincos_quarter(PRT_PI_OVER_4 * fast_div(off.x, off.y), cs, sn); // cos(pi/2 - phi) = sin(phi), sin(pi/2 - phi) = cos(phi)
     return {off.y * cs, off.y * sn};
 }
 // SampleCosineHemisphere: glm::dvec2(RandomDouble(), RandomDouble()) as compiled by g++ (right-to-left):
@@ -583,7 +628,7 @@ PRT_DEV d3 cosine_hemisphere(Rng& rng) {
     double first = rng.next();
     double second = rng.next();
     d2 dd = disk_concentric(d2{second, first});
-    double z = sqrt(fmax(0.0, 1. - dd.x * dd.x - dd.y * dd.y));
+    double z = fast_sqrt(fmax(0.0, 1. - dd.x * dd.x - dd.y * dd.y));
     return mk3(dd.x, dd.y, z);
 }
 
@@ -758,7 +803,7 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
         // textured surfaces: the light evaluation of this vertex (same pass) has already looked the albedo up
         d3 fr = ((FEAT & PRT_FEAT_TEX) && have_fr) ? fr_pre : mat_kd<FEAT>(S, m, uv) * PRT_INV_PI;
         wi_world = local_to_world(wi, f);
-        att = (fr * wi.z) * (1.0 / pdf); // fr*cos/pdf with one reciprocal (last-bit rounding only)
+        att = (fr * wi.z) * fast_rcp(pdf); // fr*cos/pdf with one reciprocal (last-bit rounding only)
         return true;
     }
     case 1: { // PhoneReflectance, Material.h:183-285
@@ -847,7 +892,7 @@ template <bool LLDS>
 PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLightNode* lds_nodes = nullptr, int32_t n_lds = 0,
                                 const DLightTri* lds_tris = nullptr, int32_t n_tris_lds = 0) {
     (void)rng.next();
-    double p = sqrt(rng.next()) * S.light_area;
+    double p = sqrt(rng.next()) * S.light_area; // IEEE: p is truncated to float and compared against the CDF — the pick stays bit-exact
     float pf = (float)p;
     int32_t node = S.light_root;
     while (node >= 0) {
@@ -862,7 +907,7 @@ PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLig
     }
     LightPick lp;
     lp.tri = ~node;
-    double x = sqrt(rng.next());
+    double x = fast_sqrt(rng.next());
     double y = rng.next();
     d3 v0, v1, v2, n;
     if (LLDS && n_tris_lds > 0) { // uniform: a scene's light triangles are staged all or not at all

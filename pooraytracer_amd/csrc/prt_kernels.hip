@@ -375,7 +375,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     // world one — three multiplies instead of a third change of basis; differs by rounding only
                     const double cosTB = -dot(ln, td);
                     // Camera.cpp:172: emission*fr*cosT*cosTB/dist^2/pdf, the scalar factor folded into one division
-                    const d3 direct = (emission * fr) * (cosT * cosTB / ((dist * dist) * pdf));
+                    const d3 direct = (emission * fr) * fast_div(cosT * cosTB, (dist * dist) * pdf);
                     ADD_RADIANCE(direct);
                 }
                 state = ST_CLOSEST;
