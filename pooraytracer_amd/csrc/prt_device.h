@@ -44,7 +44,7 @@ PRT_DEV d3 operator-(d3 a) { return {-a.x, -a.y, -a.z}; }
 PRT_DEV d3 operator*(d3 a, d3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 PRT_DEV d3 operator*(d3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
 PRT_DEV d3 operator*(double s, d3 a) { return {s * a.x, s * a.y, s * a.z}; }
-PRT_DEV d3 operator/(d3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+PRT_DEV d3 operator/(d3 a, double s); // = a * (1/s): defined below, next to the reciprocal it uses
 PRT_DEV double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PRT_DEV d3 cross(d3 x, d3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
 // fp64 square root / reciprocal for the shading code, where the kernels are VALU-bound: the hardware estimate
@@ -90,6 +90,10 @@ PRT_DEV double fast_sqrt(double x) { return sqrt(x); }
 PRT_DEV double fast_rcp(double b) { return 1.0 / b; }
 PRT_DEV double fast_div(double a, double b) { return a / b; }
 #endif
+PRT_DEV d3 operator/(d3 a, double s) { // glm divides each component; one reciprocal and three multiplies differ by rounding only
+    const double r = fast_rcp(s);
+    return {a.x * r, a.y * r, a.z * r};
+}
 PRT_DEV double length(d3 v) { return fast_sqrt(dot(v, v)); }
 PRT_DEV d3 normalize(d3 v) { return v * fast_rsqrt(dot(v, v)); } // glm::normalize = v * inversesqrt(dot(v, v))
 // normalize(v) and length(v) from one square root — glm::normalize / glm::length up to rounding
@@ -398,6 +402,17 @@ struct Trav {
             sp--;
             cur = (int32_t)stk[sp * 64];
         }
+#if PRT_DEFER_LEAF
+        // speculative descent (see the 2-wide step): stash the leaf just reached and carry on with the next stack entry
+        if (cur < 0 && cur != PRT_NOCUR && pend == 0) {
+            pend = cur;
+            if (sp == 0) cur = PRT_NOCUR;
+            else {
+                sp--;
+                cur = (int32_t)stk[sp * 64];
+            }
+        }
+#endif
         if (cur == PRT_NOCUR && pend == 0) active = false;
     }
 #else
