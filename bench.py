@@ -329,7 +329,10 @@ def time_render(ctx, name, steps, warmup, spp_override=0, with_cpu=True, cpu_tar
             out["cpu_baseline"] = base
             # parity on exactly this configuration: one fp64 frame of the same (spp, depth, seed), outside the timed region
             f64 = torch.zeros((cam.height, cam.width, 3), dtype=torch.float64, device="cuda")
-            sc.render_device(f64.data_ptr(), None, stream=stream, **dict(render_kw, rank=0, nranks=1))
+            kw64 = dict(render_kw, rank=0, nranks=1)
+            if os.environ.get("PRT_BENCH_FAULT") == "1":  # test hook: the check must notice a frame that is not the oracle's
+                kw64["seed"] = seed + 1
+            sc.render_device(f64.data_ptr(), None, stream=stream, **kw64)
             torch.cuda.synchronize()
             out["parity_check"] = parity_rows(f64.cpu().numpy(), ref_img, rows)
     sc.close()
