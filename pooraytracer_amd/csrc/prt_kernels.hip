@@ -73,8 +73,8 @@ __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
-#ifndef PRT_ONE_INIT
-#define PRT_ONE_INIT 1 // one traversal set-up call site for both ray kinds (+1...2 %, and 8 fewer spilled registers in the lean kernel)
+#ifndef PRT_SHADOW_INTERVAL
+#define PRT_SHADOW_INTERVAL 1 // shadow rays traced over [0.001, dist - 0.001] with any-hit termination (0: closest hit over [0.001, DBL_MAX))
 #endif
 #ifndef PRT_K3_TIMING
 #define PRT_K3_TIMING 0
@@ -337,11 +337,18 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 // ---- shadow ray returned: visibility = closest hit no nearer than dist - 1e-3 (Camera.cpp:152-155)
                 const d3 to = tr.o, td = tr.d;
                 const double dist = ldist;
+#if PRT_SHADOW_INTERVAL
+                // The shadow ray was traced over [0.001, dist - 0.001] only: the reference's test
+                // `dist - |ps - pNearest| < 0.001` on the closest hit of [0.001, DBL_MAX) (|direction| = 1, so the distance
+                // IS t) fails exactly when some triangle is hit inside that interval; an escaping ray counts as unoccluded (B9)
+                const bool visible = tr.hit.tri < 0;
+#else
                 bool visible = true; // an escaping shadow ray counts as unoccluded
                 if (tr.hit.tri >= 0) {
                     const d3 pn = to + td * tr.hit.t;
                     visible = (dist - length(to - pn)) < 0.001;
                 }
+#endif
                 if (visible) {
                     sh.t = 0.0;
                     sh.alpha = sh_alpha;
@@ -520,29 +527,24 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 state = ST_CLOSEST;
             }
             // ---------------- start the traversal this lane needs next
-#if PRT_ONE_INIT
             if (state == ST_CLOSEST || state == ST_SHADOW) {
-                // one traversal set-up for both kinds of ray (the two used to be separate divergent call sites, executed
-                // one after the other by every pass): Interval(0.0001, inf) for camera / continuation rays (Camera.cpp:125);
-                // Ray(ps, normalize(pl-ps)), Interval(0.001, DBL_MAX) for shadow rays (Camera.cpp:143-150), where any hit
-                // nearer than dist-1e-3 (minus a safety margin) proves occlusion, so traversal may stop there
+                // ONE traversal set-up for both kinds of ray (as two divergent call sites every pass executed both, one
+                // after the other: -1...2 %, 8 more spilled registers).  Camera / continuation rays: Interval(0.0001, inf),
+                // closest hit (Camera.cpp:125).  Shadow rays: Ray(ps, normalize(pl-ps)) (Camera.cpp:143-150); the reference
+                // takes the closest hit of Interval(0.001, DBL_MAX) and calls the light visible when that hit is no nearer
+                // than dist - 0.001, so only [0.001, dist - 0.001] needs tracing and ANY hit in it settles the question:
+                // boxes beyond the light are culled from the start and traversal stops at the first accepted triangle.
                 const bool sh_ray = state == ST_SHADOW;
                 n_closest += sh_ray ? 0u : 1u;
                 n_shadow += sh_ray ? 1u : 0u;
+#if PRT_SHADOW_INTERVAL
+                tr.init(S, sh_ray ? pos : next_o, sh_ray ? shadow_dir : next_d, sh_ray ? 0.001 : 0.0001,
+                        sh_ray ? ldist - 0.001 : PRT_INF, sh_ray ? PRT_INF : -PRT_INF);
+#else
                 tr.init(S, sh_ray ? pos : next_o, sh_ray ? shadow_dir : next_d, sh_ray ? 0.001 : 0.0001,
                         sh_ray ? 1.7976931348623157e308 : PRT_INF, sh_ray ? ldist - 0.001 - 1e-6 : -PRT_INF);
-            }
-#else
-            if (state == ST_CLOSEST) {
-                n_closest++;
-                tr.init(S, next_o, next_d, 0.0001, PRT_INF, -PRT_INF); // Camera.cpp:125
-            } else if (state == ST_SHADOW) {
-                // Ray(ps, normalize(pl-ps)), Interval(0.001, DBL_MAX) (Camera.cpp:143-150).  Any hit nearer
-                // than dist-1e-3 (minus a safety margin) proves occlusion, so traversal may stop there.
-                n_shadow++;
-                tr.init(S, pos, shadow_dir, 0.001, 1.7976931348623157e308, ldist - 0.001 - 1e-6);
-            }
 #endif
+            }
         }
         if (__ballot(state != ST_DONE) == 0ULL) break;
 
