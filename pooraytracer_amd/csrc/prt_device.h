@@ -269,13 +269,13 @@ PRT_DEV SlabAxis slab_axis(double o, double d, float B, float g0, float gs) {
 // The result does not depend on the tree except for exact ties: the closest accepted triangle is returned, and of
 // two triangles hit at bit-identical t the later-TESTED one wins (inclusive interval, as in the reference) — which
 // one is tested later depends on this tree's visit order, not on the reference's ("Exact ties").  Box tests are fp32 and strictly conservative (they can only fail to
-// cull); every accept/reject of a hit is the fp64 triangle test.  `early`: traversal stops as soon as
-// a hit with t < early is accepted (shadow rays: anything that close is an occluder for certain);
+// cull); every accept/reject of a hit is the fp64 triangle test.  `any_hit`: traversal stops at the first accepted
+// triangle (K3's shadow rays, traced over [0.001, dist - 0.001]: anything in there is an occluder);
 // -inf for closest-hit.  The stack lives in LDS, lane-strided (`stk` = this lane's column, stride 64).
 template <bool PAD>
 struct Trav {
     d3 o, d;
-    double tmin, early;
+    double tmin; // K1 only: K3 derives it (and the any-hit flag) from the kind of ray, see test_leaf
     HitInfo hit;
     SlabAxis ax, ay, az;
     float tminf, tbestf;
@@ -284,11 +284,10 @@ struct Trav {
     int32_t sp;
     bool active;
 
-    PRT_DEV void init(const DScene& S, d3 o_, d3 d_, double tmin_, double tmax_, double early_) {
+    PRT_DEV void init(const DScene& S, d3 o_, d3 d_, double tmin_, double tmax_) {
         o = o_;
         d = d_;
         tmin = tmin_;
-        early = early_;
 #if PRT_NODE16
         ax = slab_axis(o.x, d.x, S.coord_scale, S.grid_origin[0], S.grid_step[0]);
         ay = slab_axis(o.y, d.y, S.coord_scale, S.grid_origin[1], S.grid_step[1]);
@@ -498,7 +497,7 @@ struct Trav {
 
     // fp64 tests of one leaf's triangles (128-byte records); returns true when an early-out hit was accepted.
     template <bool COUNT>
-    PRT_DEV bool test_leaf(const DScene& S, int32_t ref, WorkCount& wc) {
+    PRT_DEV bool test_leaf(const DScene& S, int32_t ref, WorkCount& wc, double tmin_use, bool any_hit) {
         const uint32_t enc = ~(uint32_t)ref;
         const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
         bool stop = false;
@@ -515,16 +514,16 @@ struct Trav {
 #if PRT_LEAF_PREFETCH
             const double4 q0c = q0n;
             if (i + 1 < cnt) q0n = *reinterpret_cast<const double4*>(tri_at<PAD>(S, first + i + 1));
-            if (tri_test(tri_at<PAD>(S, first + i), o, d, tmin, hit.t, t, al, be, &q0c, COUNT ? &wc.tris_full : nullptr)) {
+            if (tri_test(tri_at<PAD>(S, first + i), o, d, tmin_use, hit.t, t, al, be, &q0c, COUNT ? &wc.tris_full : nullptr)) {
 #else
-            if (tri_test(tri_at<PAD>(S, first + i), o, d, tmin, hit.t, t, al, be, nullptr, COUNT ? &wc.tris_full : nullptr)) {
+            if (tri_test(tri_at<PAD>(S, first + i), o, d, tmin_use, hit.t, t, al, be, nullptr, COUNT ? &wc.tris_full : nullptr)) {
 #endif
                 hit.t = t;
                 hit.alpha = al;
                 hit.beta = be;
                 hit.tri = (int32_t)(first + i);
                 tbestf = f32_up(t);
-                if (t < early) stop = true;
+                if (any_hit) stop = true;
             }
         }
         return stop;
@@ -532,14 +531,14 @@ struct Trav {
 
     // Leaf round of this lane: the stashed leaf (reached first, usually nearer), then the current one, then pop.
     template <bool COUNT>
-    PRT_DEV void leaf_step(const DScene& S, uint32_t* stk, WorkCount& wc) {
+    PRT_DEV void leaf_step(const DScene& S, uint32_t* stk, WorkCount& wc, double tmin_use, bool any_hit) {
         bool stop = false;
         if (pend != 0) {
-            stop = test_leaf<COUNT>(S, pend, wc);
+            stop = test_leaf<COUNT>(S, pend, wc, tmin_use, any_hit);
             pend = 0;
         }
         if (!stop && cur < 0 && cur != PRT_NOCUR) {
-            stop = test_leaf<COUNT>(S, cur, wc);
+            stop = test_leaf<COUNT>(S, cur, wc, tmin_use, any_hit);
             cur = PRT_NOCUR;
         }
         if (stop) {
@@ -558,9 +557,11 @@ struct Trav {
     // a load instruction the same whether 3 or 64 lanes execute it, so lanes that reach a leaf PARK
     // there until at least PRT_LEAF_BATCH lanes of the wave are parked (or hardly any lane is still
     // descending), and then test their triangles together.
+    // `tmin_use` / `any_hit`: the interval's lower end and whether the first accepted triangle ends the traversal.  K1
+    // passes its per-ray tmin; K3 derives both from the kind of ray the lane is tracing, so neither is traversal state.
     template <bool COUNT>
-    PRT_DEV void round(const DScene& S, uint32_t* stk, WorkCount& wc, int leaf_batch = PRT_LEAF_BATCH,
-                       int inner_min = PRT_INNER_MIN) {
+    PRT_DEV void round(const DScene& S, uint32_t* stk, WorkCount& wc, int leaf_batch, int inner_min, double tmin_use,
+                       bool any_hit) {
         if (COUNT && __ballot(active && cur >= 0) != 0ULL) wc.inner_rounds++;
         if (active && cur >= 0) inner_step<COUNT>(S, stk, wc);
         const bool parked = active && cur < 0;                                   // cannot descend any further right now
@@ -569,7 +570,7 @@ struct Trav {
         const int n_inner = __popcll(__ballot(active && cur >= 0));
         if (n_parked >= leaf_batch || n_inner <= inner_min) {
             if (COUNT && __ballot(has_leaf) != 0ULL) wc.leaf_rounds++;
-            if (has_leaf) leaf_step<COUNT>(S, stk, wc);
+            if (has_leaf) leaf_step<COUNT>(S, stk, wc, tmin_use, any_hit);
         }
     }
 };

@@ -73,9 +73,6 @@ __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
-#ifndef PRT_SHADOW_INTERVAL
-#define PRT_SHADOW_INTERVAL 1 // shadow rays traced over [0.001, dist - 0.001] with any-hit termination (0: closest hit over [0.001, DBL_MAX))
-#endif
 #ifndef PRT_K3_TIMING
 #define PRT_K3_TIMING 0
 #endif
@@ -100,7 +97,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
     WorkCount wc{0, 0, 0, 0, 0};
     uint32_t nrays = 0;
     Trav<PAD> tr;
-    tr.init(S, mk3(0, 0, 0), mk3(0, 0, 1), 0.0, 0.0, 0.0);
+    tr.init(S, mk3(0, 0, 0), mk3(0, 0, 1), 0.0, 0.0);
     tr.active = false;
     bool have = false;
     size_t my = 0;
@@ -147,7 +144,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
                     if (idx < pool_end) {
                         const double4* rp = reinterpret_cast<const double4*>(rays + idx);
                         const double4 r0 = rp[0], r1 = rp[1];
-                        tr.init(S, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), r0.w, r1.w, -PRT_INF);
+                        tr.init(S, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), r0.w, r1.w);
                         my = (size_t)idx;
                         have = true;
                         nrays++;
@@ -161,7 +158,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
         }
         if (__ballot(tr.active || have) == 0ULL && exhausted) break;
         do {
-            tr.template round<COUNT>(S, stk, wc);
+            tr.template round<COUNT>(S, stk, wc, PRT_LEAF_BATCH, PRT_INNER_MIN, tr.tmin, false);
         } while (wave_count(tr.active) > PRT_K1_KEEP);
     }
     unsigned long long a = wave_sum((unsigned long long)nrays);
@@ -283,7 +280,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     rng.s = 0;
     const double inv_spp = 1.0 / P.spp; // pixelSamplesScale, Camera.cpp:83
     Trav<PAD> tr;
-    tr.init(S, mk3(0, 0, 0), rd, 0.0, 0.0, 0.0);
+    tr.init(S, mk3(0, 0, 0), rd, 0.0, 0.0);
     tr.active = false;
 
     for (;;) {
@@ -337,18 +334,10 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 // ---- shadow ray returned: visibility = closest hit no nearer than dist - 1e-3 (Camera.cpp:152-155)
                 const d3 to = tr.o, td = tr.d;
                 const double dist = ldist;
-#if PRT_SHADOW_INTERVAL
                 // The shadow ray was traced over [0.001, dist - 0.001] only: the reference's test
                 // `dist - |ps - pNearest| < 0.001` on the closest hit of [0.001, DBL_MAX) (|direction| = 1, so the distance
                 // IS t) fails exactly when some triangle is hit inside that interval; an escaping ray counts as unoccluded (B9)
                 const bool visible = tr.hit.tri < 0;
-#else
-                bool visible = true; // an escaping shadow ray counts as unoccluded
-                if (tr.hit.tri >= 0) {
-                    const d3 pn = to + td * tr.hit.t;
-                    visible = (dist - length(to - pn)) < 0.001;
-                }
-#endif
                 if (visible) {
                     sh.t = 0.0;
                     sh.alpha = sh_alpha;
@@ -537,20 +526,16 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 const bool sh_ray = state == ST_SHADOW;
                 n_closest += sh_ray ? 0u : 1u;
                 n_shadow += sh_ray ? 1u : 0u;
-#if PRT_SHADOW_INTERVAL
                 tr.init(S, sh_ray ? pos : next_o, sh_ray ? shadow_dir : next_d, sh_ray ? 0.001 : 0.0001,
-                        sh_ray ? ldist - 0.001 : PRT_INF, sh_ray ? PRT_INF : -PRT_INF);
-#else
-                tr.init(S, sh_ray ? pos : next_o, sh_ray ? shadow_dir : next_d, sh_ray ? 0.001 : 0.0001,
-                        sh_ray ? 1.7976931348623157e308 : PRT_INF, sh_ray ? ldist - 0.001 - 1e-6 : -PRT_INF);
-#endif
+                        sh_ray ? ldist - 0.001 : PRT_INF);
             }
         }
         if (__ballot(state != ST_DONE) == 0ULL) break;
 
         // ---------------- traversal steps until enough lanes have finished to be worth refilling
         do {
-            tr.template round<COUNT>(S, stk, wc, P.leaf_batch, P.inner_min);
+            // the interval's lower end and the any-hit rule follow from the kind of ray: not kept as traversal state
+            tr.template round<COUNT>(S, stk, wc, P.leaf_batch, P.inner_min, state == ST_SHADOW ? 0.001 : 0.0001, state == ST_SHADOW);
         } while (wave_count(tr.active) > P.keep);
     }
 
