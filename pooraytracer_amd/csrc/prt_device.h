@@ -301,8 +301,6 @@ struct Trav {
         tbestf = f32_up(tmax_);
         hit.t = tmax_;
         hit.tri = -1;
-        hit.alpha = 0.0;
-        hit.beta = 0.0;
         sp = 0;
         cur = 0;
         pend = 0;
@@ -519,8 +517,10 @@ struct Trav {
             if (tri_test(tri_at<PAD>(S, first + i), o, d, tmin_use, hit.t, t, al, be, nullptr, COUNT ? &wc.tris_full : nullptr)) {
 #endif
                 hit.t = t;
-                hit.alpha = al;
-                hit.beta = be;
+                if (!any_hit) { // an any-hit (shadow) traversal only reports THAT something was hit: the barycentrics of the
+                    hit.alpha = al; // shading point's own hit stay where they are, for the shading that follows
+                    hit.beta = be;
+                }
                 hit.tri = (int32_t)(first + i);
                 tbestf = f32_up(t);
                 if (any_hit) stop = true;

@@ -98,6 +98,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
     uint32_t nrays = 0;
     Trav<PAD> tr;
     tr.init(S, mk3(0, 0, 0), mk3(0, 0, 1), 0.0, 0.0);
+    tr.hit.alpha = tr.hit.beta = 0.0;
     tr.active = false;
     bool have = false;
     size_t my = 0;
@@ -272,7 +273,6 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     // tr.o is the shading point itself, so only the incoming direction, the hit's barycentrics and
     // the light pick need to be kept.
     d3 rd = mk3(0, 0, 1);        // incoming direction at the shading point (valid in ST_SHADOW)
-    double sh_alpha = 0, sh_beta = 0;
     int32_t sh_tri = -1;
     double ldist = 0;            // distance to the sampled light point (valid in ST_SHADOW)
     int32_t ltri = 0;
@@ -281,6 +281,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     const double inv_spp = 1.0 / P.spp; // pixelSamplesScale, Camera.cpp:83
     Trav<PAD> tr;
     tr.init(S, mk3(0, 0, 0), rd, 0.0, 0.0);
+    tr.hit.alpha = tr.hit.beta = 0.0; // init() leaves the barycentrics alone (they survive shadow traversals)
     tr.active = false;
 
     for (;;) {
@@ -308,8 +309,6 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                         end_sample = true;
                     } else {
                         rd = tr.d;
-                        sh_alpha = h.alpha;
-                        sh_beta = h.beta;
                         sh_tri = h.tri;
                         pos = tr.o + tr.d * h.t; // record.position = ray(t)
                         do_scatter = true;
@@ -340,8 +339,8 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 const bool visible = tr.hit.tri < 0;
                 if (visible) {
                     sh.t = 0.0;
-                    sh.alpha = sh_alpha;
-                    sh.beta = sh_beta;
+                    sh.alpha = tr.hit.alpha; // still the shading point's: shadow traversals leave them alone
+                    sh.beta = tr.hit.beta;
                     sh.tri = sh_tri;
                     const ShadeCtx c = make_ctx<FEAT, PAD>(S, to, rd, sh);
                     const DMaterial& m = MATERIAL(c.material);
@@ -383,8 +382,8 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 end_sample = true;
                 if (rng.next() < P.rr) {
                     sh.t = 0.0;
-                    sh.alpha = sh_alpha;
-                    sh.beta = sh_beta;
+                    sh.alpha = tr.hit.alpha; // still the shading point's: shadow traversals leave them alone
+                    sh.beta = tr.hit.beta;
                     sh.tri = sh_tri;
                     const ShadeCtx c = make_ctx<FEAT, PAD>(S, pos, rd, sh);
                     const DMaterial& m = MATERIAL(c.material);
