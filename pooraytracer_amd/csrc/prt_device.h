@@ -826,6 +826,7 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
         d3 wo = world_to_local(-rd, f);
         d3 wi = mk3(0, 0, 0), fr = mk3(0, 0, 0);
         double pdf = 0;
+        bool spec = false, spec_ok = false;
         double u = rng.next();
         if (u < m.pkd) {
             wi = cosine_hemisphere(rng);
@@ -848,16 +849,17 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
             d3 T = normalize(cross(V, lr));
             d3 B = cross(lr, T);
             wi = rw.x * T + rw.y * B + rw.z * lr;
-            // SpecularPDF, Material.h:255-261
-            // both the pdf and f use cos^Ns of the angle to the mirror direction: one pow, evaluated only where used
-            const double dl = dot(wi, lr);
-            const double lca = fmax(0.0, dl);
-            const double pw = wi.z > 0. ? pow_pos(dl, m.ns) : 0.0;
-            pdf = wi.z <= 0. ? 0.0 : (m.ns + 1.0) * PRT_INV_2PI * pw;
-            if (wi.z > 0. && lca > 0.) fr = mat_ks<FEAT>(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pw;
+            // SpecularPDF (Material.h:255-261) and f (:222-224) both carry cos^Ns(alpha) of the angle to the mirror
+            // direction, and cos(alpha) = dot(wi, lr) IS ca = u1^(1/(Ns+1)) (T, B, lr are orthonormal), so the power is
+            // u1^(Ns/(Ns+1)): positive whenever u1 is (u1 >= 2^-31 or 0 — it cannot underflow), and it cancels in
+            // f cos / pdf = Ks (Ns+2)/(Ns+1) cos(theta_i).  No second pow (one log + one exp less per specular sample).
+            spec_ok = wi.z > 0. && u1 > 0.;
+            spec = true;
+            fr = mat_ks<FEAT>(S, m, uv) * ((m.ns + 2.) / (m.ns + 1.));
         }
         wi_world = local_to_world(wi, f);
-        if (pdf > 0. && wi.z > 0) att = fr * wi.z / pdf;
+        if (spec) att = spec_ok ? fr * wi.z : mk3(0, 0, 0); // below the horizon: pdf = 0, attenuation unassigned upstream, 0 here (B13)
+        else if (pdf > 0. && wi.z > 0) att = fr * wi.z / pdf;
         else att = mk3(0, 0, 0); // reference leaves it unassigned (Material.h:280-282); defined 0 (B13)
         return true;
     }
