@@ -76,6 +76,14 @@ __device__ __forceinline__ T wave_sum(T v) {
 #ifndef PRT_K3_TIMING
 #define PRT_K3_TIMING 0
 #endif
+#ifndef PRT_K3_PROFILE
+#define PRT_K3_PROFILE 0 // developer diagnostic (COUNT instantiation): shader-clock cycles per section of the wave loop, folded into the counters
+#endif
+#if PRT_K3_PROFILE
+#define PROF_MARK(k) do { if (COUNT) { const unsigned long long t_ = __builtin_readcyclecounter(); prof_[k] += t_ - prof_t_; prof_t_ = t_; } } while (0)
+#else
+#define PROF_MARK(k) do { } while (0)
+#endif
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_xor(v, off, 64);
@@ -284,8 +292,12 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     tr.hit.alpha = tr.hit.beta = 0.0; // init() leaves the barycentrics alone (they survive shadow traversals)
     tr.active = false;
 
+#if PRT_K3_PROFILE
+    unsigned long long prof_[6] = {0, 0, 0, 0, 0, 0}, prof_t_ = __builtin_readcyclecounter();
+#endif
     for (;;) {
         if (COUNT) n_refills++;
+        PROF_MARK(0); // traversal rounds (and loop control) since the last mark
         if (!tr.active) {
             // ---------------- a traversal has just finished on this lane: consume its result
             bool end_sample = false, do_scatter = false;
@@ -377,6 +389,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 do_scatter = true;
             }
 
+            PROF_MARK(1); // consume: closest hit (emission, light pick) or shadow ray (light evaluation)
             if (do_scatter) {
                 // ---- Russian roulette + Scatter, Camera.cpp:176-202
                 end_sample = true;
@@ -405,6 +418,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     }
                 }
             }
+            PROF_MARK(2); // roulette + Scatter
             if (end_sample) {
                 const d3 acc = PST_LD(S_ACC);
                 s++;
@@ -514,6 +528,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 n_samples++;
                 state = ST_CLOSEST;
             }
+            PROF_MARK(3); // end of sample, item fetch, new sample
             // ---------------- start the traversal this lane needs next
             if (state == ST_CLOSEST || state == ST_SHADOW) {
                 // ONE traversal set-up for both kinds of ray (as two divergent call sites every pass executed both, one
@@ -529,6 +544,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                         sh_ray ? ldist - 0.001 : PRT_INF);
             }
         }
+        PROF_MARK(4); // traversal set-up
         if (__ballot(state != ST_DONE) == 0ULL) break;
 
         // ---------------- traversal steps until enough lanes have finished to be worth refilling
@@ -551,7 +567,13 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
         if (COUNT) {
             atomicAdd(&ctr->node_fetches, d);
             atomicAdd(&ctr->tri_full, f);
-#if PRT_K3_TIMING
+#if PRT_K3_PROFILE
+            atomicAdd(&ctr->tri_tests, prof_[0]);
+            atomicAdd(&ctr->inner_rounds, prof_[1]);
+            atomicAdd(&ctr->leaf_rounds, prof_[2]);
+            atomicAdd(&ctr->refills, prof_[3]);
+            atomicAdd(&ctr->tri_full, prof_[4]);
+#elif PRT_K3_TIMING
             const unsigned long long tm_end = wall_clock64();
             atomicMax(&ctr->inner_rounds, ~tm_start);               // -> earliest wave start
             atomicMax(&ctr->refills, tm_end);                      // -> latest wave end
