@@ -10,7 +10,11 @@
  * absent so it is unbuildable here without stand-in headers (which the build rules forbid), and it
  * is C++ so it cannot be imported.  This oracle is therefore a line-by-line CPU restatement of the
  * reference algorithm (each function cites the reference file:line it follows), pinned only by
- * hand-derived known-answer tests and its own committed fixtures in tests/golden/.
+ * hand-derived known-answer tests (tests/test_oracle.py), closed forms / normalisation integrals /
+ * chi-square tests of the material arithmetic from the literature (tests/test_materials.py), a second
+ * independent restatement of Camera::RayColor in Python that must agree per sample
+ * (tests/test_oracle_crosscheck.py) and its own committed fixtures in tests/golden/ — none of which
+ * is a reference output.
  *
  * The struct layouts deliberately equal those of include/prt.h so a test can hand the same
  * buffers to both libraries; they are re-declared here so the oracle has no product dependency.
