@@ -737,7 +737,8 @@ void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hit
                   int n_cu, hipStream_t st) {
     if (n == 0) return;
     size_t want = (n + PRT_BLOCK - 1) / PRT_BLOCK;
-    unsigned grid = (unsigned)std::min<size_t>(want, (size_t)n_cu * 5); // 5 x 32 KB LDS stacks per CU
+    const size_t per_cu = std::max<size_t>(1, (160u * 1024u) / (sizeof(uint32_t) * PRT_STACK_DEPTH * PRT_BLOCK)); // LDS stacks per CU
+    unsigned grid = (unsigned)std::min<size_t>(want, (size_t)n_cu * per_cu);
     const bool pad = S.tri_stride == 128u && sizeof(DTri) != 128;
     auto k = count ? (pad ? k_trace_closest<true, true> : k_trace_closest<true, false>)
                    : (pad ? k_trace_closest<false, true> : k_trace_closest<false, false>);

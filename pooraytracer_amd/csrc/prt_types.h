@@ -16,7 +16,10 @@
 #define PRT_BVH_WIDTH 4      // children per node: 4 (64-byte nodes, collapsed from the binary tree; measured +11...32 %) or 2 (32-byte nodes)
 #endif
 #ifndef PRT_STACK_DEPTH
-#define PRT_STACK_DEPTH 32   // LDS traversal stack entries per lane; the builders bound the stack a traversal can need to it
+#define PRT_STACK_DEPTH 40   // LDS traversal stack entries per lane; the builders bound the stack a traversal can need to it.
+                             // 40 = 40 KB per 256-thread block: four K1 blocks fill the 160 KB of a CU exactly.  The 4-wide collapse
+                             // spends up to three entries per level, so on deep trees the budget decides how wide the nodes get:
+                             // 8M-triangle soup 4.73M -> 3.77M nodes, 44.9 -> 36.0 visits per ray, +21 % (32 -> 40); 48 costs K1 a wave
 #endif
 #define PRT_BVH2_LEVELS 30   // inner-node levels of the binary tree both builders bound their trees to
 #ifndef PRT_LEAF_MAX
