@@ -771,6 +771,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     for (int c = 0; c < chunks; ++c) P.chunk_begin[c + 1] = P.chunk_begin[c] + sizes[c];
     P.chunks = chunks;
     P.n_items = P.items_per_chunk * (uint64_t)chunks;
+    if (P.n_items >= 0xffffffffULL) return fail(PRT_E_LIMIT, "prt_render_device: more than 2^32 work items (pixels x sample chunks) in one launch");
 
     const size_t need = std::max<size_t>(P.n_items * 3, 3);
     hipError_t we;

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
 #endif
 
     int state = ST_FETCH;
-    uint64_t item = 0;
+    uint32_t item = 0; // work items of a launch are counted in 32 bits (the host refuses more): every division below is a 32-bit one
     int px = 0, py = 0, s = 0, s_end = 0, depth = 0;
     bool first = true, prev_skip = false;
     PST_ST(S_ACC, mk3(0, 0, 0));  // sum over this item's samples of colour * (1/spp)
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 s++;
                 if (s < s_end) state = ST_NEW_SAMPLE;
                 else {
-                    double* o = partial + item * 3;
+                    double* o = partial + (size_t)item * 3;
                     o[0] = acc.x;
                     o[1] = acc.y;
                     o[2] = acc.z;
@@ -458,7 +458,10 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     if (lane == leader) base = atomicAdd(&ctr->next_item, grab);
                     base = __shfl(base, leader, 64);
                 }
-                item = rank < left ? pn + rank : base + (rank - left);
+                {
+                    const unsigned long long it = rank < left ? pn + rank : base + (rank - left);
+                    item = it < P.n_items ? (uint32_t)it : (uint32_t)P.n_items;
+                }
                 if (lane == leader) {
                     if (left < need) {
                         pool[0] = base + (need - left);
@@ -474,13 +477,13 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 // s_qoff[wave] = queues this wave has seen run dry.
                 {
                     uint32_t off = __builtin_amdgcn_readfirstlane(s_qoff[wave]);
-                    item = P.n_items;
+                    item = (uint32_t)P.n_items;
                     while (off < (uint32_t)PRT_ITEM_QUEUES) {
                         const uint32_t q = (blockIdx.x + off) % (uint32_t)PRT_ITEM_QUEUES;
                         const unsigned long long idx = atomicAdd(&ctr->queue[q * PRT_QUEUE_STRIDE], 1ULL);
                         const unsigned long long it = ((idx >> 6) * PRT_ITEM_QUEUES + q) * 64ULL + (idx & 63ULL);
                         if (it < P.n_items) {
-                            item = it;
+                            item = (uint32_t)it;
                             break;
                         }
                         ++off;
@@ -488,23 +491,27 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     atomicMax(&s_qoff[wave], off);
                 }
 #else
-                item = atomicAdd(&ctr->next_item, 1ULL); // per-lane fetch (the compiler aggregates lanes of one pass)
+                {
+                    const unsigned long long it = atomicAdd(&ctr->next_item, 1ULL); // per-lane fetch (the compiler aggregates lanes of one pass)
+                    item = it < P.n_items ? (uint32_t)it : (uint32_t)P.n_items;
+                }
 #endif
-                if (item >= P.n_items) {
+                if (item >= (uint32_t)P.n_items) {
                     state = ST_DONE;
 #if PRT_K3_TIMING
                     if (COUNT && tm_dry == 0) tm_dry = wall_clock64();
 #endif
                 } else {
-                    const uint32_t chunk = (uint32_t)(item / P.items_per_chunk);
-                    const uint64_t oi = item % P.items_per_chunk;
+                    const uint32_t ipc = (uint32_t)P.items_per_chunk;
+                    const uint32_t chunk = item / ipc;
+                    const uint32_t oi = item - chunk * ipc;
                     if (owned_to_pixel(P, C, oi, px, py)) {
                         s = P.chunk_begin[chunk];
                         s_end = P.chunk_begin[chunk + 1];
                         PST_ST(S_ACC, mk3(0, 0, 0));
                         if (s < s_end) state = ST_NEW_SAMPLE;
                         else {
-                            double* o = partial + item * 3;
+                            double* o = partial + (size_t)item * 3;
                             o[0] = o[1] = o[2] = 0.0;
                         }
                     }
