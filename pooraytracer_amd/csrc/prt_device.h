@@ -839,7 +839,7 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
             // its Pythagorean complement, and sin/cos(2 pi u2) reduce exactly in u2 to a quarter-period polynomial —
             // no acos, no general-range sincos (their results differ from these by rounding only)
             double sa, ca, sp, cp;
-            ca = fmin(pow_pos(u1, 1.0 / (m.ns + 1.0)), 1.0);
+            ca = fmin(pow_pos(u1, m.inv_ns1), 1.0);
             sa = sqrt(fmax(0.0, 1.0 - ca * ca));
             sincos_turns(u2, sp, cp);
             d3 rw = mk3(sa * cp, sa * sp, ca);
@@ -855,7 +855,7 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
             // f cos / pdf = Ks (Ns+2)/(Ns+1) cos(theta_i).  No second pow (one log + one exp less per specular sample).
             spec_ok = wi.z > 0. && u1 > 0.;
             spec = true;
-            fr = mat_ks<FEAT>(S, m, uv) * ((m.ns + 2.) / (m.ns + 1.));
+            fr = mat_ks<FEAT>(S, m, uv) * m.spec_scale;
         }
         wi_world = local_to_world(wi, f);
         if (spec) att = spec_ok ? fr * wi.z : mk3(0, 0, 0); // below the horizon: pdf = 0, attenuation unassigned upstream, 0 here (B13)

@@ -114,6 +114,7 @@ struct DMaterial {
     double eta[3], k[3];
     double alpha_x, alpha_y;
     int32_t has_emission, skip_light_sampling;
+    double inv_ns1, spec_scale; // Phong: 1 / (Ns + 1) and (Ns + 2) / (Ns + 1), divided once on the host
 };
 
 struct DTexture {

@@ -126,6 +126,8 @@ void setup_materials(const PrtSceneDesc& d, std::vector<DMaterial>& out) {
             m.k[c] = s.k[c];
         }
         m.ns = s.ns;
+        m.inv_ns1 = 1.0 / (s.ns + 1.0);
+        m.spec_scale = (s.ns + 2.0) / (s.ns + 1.0);
         // SetProbabilitiesByNs, Material.h:318-327
         if (s.ns <= 9.) {
             m.pkd = 1.0;
