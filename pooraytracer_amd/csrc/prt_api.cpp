@@ -718,7 +718,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     const bool count = count_work != 0;
     const int bpc = s->blocks_per_cu[count ? 1 : 0];
     const uint64_t lanes = (uint64_t)s->n_cu * bpc * PRT_BLOCK;
-    // Work item = (pixel, chunk of samples), dealt chunk-major from one global counter.
+    // Work item = (pixel, chunk of samples), dealt chunk-major from PRT_ITEM_QUEUES counters (prt_types.h).
     //  * explicit sample_chunks: that many equal chunks;
     //  * auto: guided self-scheduling.  The launch ends when the LAST lane finishes, so no item may be
     //    handed out that can outlast the work still queued behind it.  Items of one chunk cover every owned

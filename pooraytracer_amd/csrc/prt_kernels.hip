@@ -53,11 +53,6 @@ constexpr int render_waves(int feat) {
 #ifndef PRT_K3_KEEP
 #define PRT_K3_KEEP 24
 #endif
-#ifndef PRT_K3_POOL
-#define PRT_K3_POOL 0 // 0: every lane fetches its own item (atomics aggregated per pass by the compiler).  64: wave-local
-                      // LDS pool, one atomic per 64 items — far better at spp <= 64, but reserving items costs load
-                      // balance at the end of long frames (spp 500: -1 % at N=1, -8 % on a 1/8 tile share), so it is off
-#endif
 #ifndef PRT_K1_WAVES
 #define PRT_K1_WAVES 4 // resident waves per SIMD the K1 register allocation leaves room for
 #endif
@@ -220,14 +215,10 @@ template <bool COUNT, int FEAT, bool LLDS, bool PAD>
 __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     DScene S, DCamera C, DRenderParams P, double* __restrict__ partial, DCounters* ctr) {
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
-    __shared__ unsigned long long s_pool[PRT_BLOCK / 64][2];
     __shared__ uint32_t s_qoff[PRT_BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stk = &s_stack[wave][0][lane];
-    volatile unsigned long long* pool = s_pool[wave];
     if (lane == 0) {
-        pool[0] = 0;
-        pool[1] = 0;
         s_qoff[wave] = 0;
     }
     // light tree in LDS (dynamic allocation sized by the host; see sample_lights)
@@ -434,43 +425,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
 
             // ---------------- give the lane its next piece of work
             if (state == ST_FETCH) {
-                // Items come from a wave-local pool kept in LDS ([0] = next, [1] = end), refilled PRT_K3_POOL
-                // at a time by ONE returning atomic per wave: a returning device-scope atomic stalls the whole
-                // wave for microseconds, which costs about one sample's worth of work per item if every
-                // lane fetches for itself.  All lanes of this branch read the same LDS words (broadcast);
-                // the leader updates them; LDS operations of a wave complete in program order.
-#if PRT_K3_POOL > 0
-                const unsigned long long here = __ballot(true);
-                const int leader = (int)__builtin_ctzll(here);
-                const unsigned long long rank = (unsigned long long)__popcll(here & ((1ULL << lane) - 1ULL));
-                const unsigned long long need = (unsigned long long)__popcll(here);
-                unsigned long long pn = pool[0], pe = pool[1];
-                const unsigned long long left = pe - pn; // items still in the pool
-                unsigned long long base = 0;
-                // Pool size: PRT_K3_POOL while plenty of items remain, shrinking with the (stale, wave-local)
-                // estimate of what is left so that no wave sits on reserved items while others run dry.
-                unsigned long long grab = need - left;
-                if (left < need) { // not enough: hand out what is left, then continue from a fresh pool
-                    const unsigned long long rem = P.n_items > pe ? P.n_items - pe : 0ULL;
-                    unsigned long long g = rem / (8ULL * (unsigned long long)gridDim.x * (PRT_BLOCK / 64));
-                    if (g > (unsigned long long)PRT_K3_POOL) g = (unsigned long long)PRT_K3_POOL;
-                    if (g > grab) grab = g;
-                    if (lane == leader) base = atomicAdd(&ctr->next_item, grab);
-                    base = __shfl(base, leader, 64);
-                }
-                {
-                    const unsigned long long it = rank < left ? pn + rank : base + (rank - left);
-                    item = it < P.n_items ? (uint32_t)it : (uint32_t)P.n_items;
-                }
-                if (lane == leader) {
-                    if (left < need) {
-                        pool[0] = base + (need - left);
-                        pool[1] = base + grab;
-                    } else {
-                        pool[0] = pn + need;
-                    }
-                }
-#elif PRT_ITEM_QUEUES > 1
+#if PRT_ITEM_QUEUES > 1
                 // One returning atomic per wave and pass on the wave's current queue (the queue index is wave-uniform,
                 // so the compiler aggregates the lanes that execute it); a queue that hands out an index past the end
                 // is dry for good (its indices only grow) and the lanes that drew a blank move on to the next one.

@@ -158,3 +158,20 @@ def test_cmake_build_produces_the_same_libraries(tmp_path):
     assert out.returncode == 0 and int(out.stdout.strip()) == _abi.PRT_ABI_VERSION, out.stderr
     ldd = subprocess.run(["ldd", os.path.join(bdir, "render_scene")], capture_output=True, text=True).stdout
     assert "libpooraytracer_host.so" in ldd and "libprt_hip.so" in ldd
+
+
+@pytest.mark.parametrize("flags", [["-DPRT_BVH_WIDTH=2"], ["-DPRT_TRI_FORM=0", "-DPRT_FAST_F64=0"], ["-DPRT_ITEM_QUEUES=1", "-DPRT_K3_PROFILE=1"]])
+def test_alternative_build_configurations_still_compile(flags):
+    """The A/B switches DESIGN.md quotes measurements for (2-wide nodes, the reference's triangle expressions on 128-byte
+    records, IEEE sqrt / division in the shading code, one work-item counter, the per-section profile) are compile-time
+    options of the same sources: they must keep compiling (semantic analysis incl. every kernel instantiation, host
+    and gfx950 passes; no code generation, so this takes seconds)."""
+    import shutil
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not installed")
+    csrc = os.path.join(ROOT, "pooraytracer_amd", "csrc")
+    srcs = [os.path.join(csrc, f) for f in ("prt_kernels.hip", "bvh_build_gpu.hip", "bvh_build.cpp", "prt_api.cpp")]
+    r = subprocess.run([hipcc, "-std=c++17", "--offload-arch=gfx950", "-fsyntax-only", "-Wno-unused-function"] + flags + srcs,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
