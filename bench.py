@@ -145,6 +145,17 @@ def roofline(workload, kernel, bpr, npr, tpr, fpr, rays_per_launch, extra_bytes,
     if hbm_gbps is not None and hbm_gbps >= 0.4 * HBM_PEAK_GBPS:
         out.update(bound="hbm", achieved=round(alg_gbps, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                    frac=round(alg_gbps / HBM_PEAK_GBPS, 4), traffic=traffic)
+        # scattered reads are served per 128-byte line whatever part of it is used: the rate of L2 misses against the
+        # random-line rate measured on this chip (tools/hbm_calib.hip, profiles/r02_hbm_calibration.json)
+        misses = pmc["counters_per_launch"].get("TCC_MISS_sum")
+        try:
+            ceiling = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_calibration.json")))["conclusions"]["random_line_ceiling_per_us"] * 1e6
+        except Exception:
+            ceiling = None
+        if misses and ceiling:
+            lines_per_s = misses * scale / sec
+            out.update(lines_per_ray=round(misses * scale / rays_per_launch, 2), random_lines_per_s=round(lines_per_s / 1e9, 2),
+                       random_line_ceiling_per_s=round(ceiling / 1e9, 2), frac_of_line_ceiling=round(lines_per_s / ceiling, 4))
     elif valu is not None:
         ginst = valu / sec / 1e9
         out.update(bound="valu", achieved=round(ginst, 1), peak=round(VALU_PEAK_GINST, 1), unit="Ginstr/s",
