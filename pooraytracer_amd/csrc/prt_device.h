@@ -287,6 +287,10 @@ struct Trav {
     PRT_DEV void init(const DScene& S, d3 o_, d3 d_, double tmin_, double tmax_) {
         o = o_;
         d = d_;
+        start(S, tmin_, tmax_);
+    }
+    // Starts the traversal of the ray already in o / d.
+    PRT_DEV void start(const DScene& S, double tmin_, double tmax_) {
         tmin = tmin_;
 #if PRT_NODE16
         ax = slab_axis(o.x, d.x, S.coord_scale, S.grid_origin[0], S.grid_step[0]);

@@ -292,9 +292,10 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
         if (!tr.active) {
             // ---------------- a traversal has just finished on this lane: consume its result
             bool end_sample = false, do_scatter = false;
-            d3 next_o = mk3(0, 0, 0), next_d = mk3(0, 0, 1); // the ray to trace next when state ends up ST_CLOSEST
-            d3 pos = tr.o;                 // shading point (ST_SHADOW: the shadow ray's origin)
-            d3 shadow_dir = mk3(0, 0, 1);
+            // The ray this lane traces next is written straight into tr.o / tr.d as soon as it is known (shadow ray:
+            // origin = shading point, direction towards the light; continuation: same origin, scattered direction; new
+            // sample: the camera ray) — no staging copies, no selects at the traversal set-up.  After a closest hit has
+            // been consumed tr.o IS the shading point.
             HitInfo sh;
             bool have_fr = false;
             d3 fr_seen = mk3(0, 0, 0);
@@ -313,19 +314,19 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     } else {
                         rd = tr.d;
                         sh_tri = h.tri;
-                        pos = tr.o + tr.d * h.t; // record.position = ray(t)
+                        tr.o = tr.o + tr.d * h.t; // record.position = ray(t): from here on the origin of whatever comes next
                         do_scatter = true;
                         if (P.sample_lights && S.n_lights > 0 && !m.skip_light_sampling) {
                             // next-event estimation, Camera.cpp:137-155: pick the light point now (4 draws)
                             const d3 gn = ld3(tri_at<PAD>(S, (uint32_t)h.tri)->n);
                             const d3 fn = dot(rd, gn) < 0. ? gn : -gn;
-                            const LightPick lp = sample_lights<LLDS>(S, pos, rng, lds_lights, P.light_lds, lds_ltris, P.ltri_lds);
+                            const LightPick lp = sample_lights<LLDS>(S, tr.o, rng, lds_lights, P.light_lds, lds_ltris, P.ltri_lds);
                             double dist;
-                            const d3 ldir = normalize_len(lp.pos - pos, dist);
+                            const d3 ldir = normalize_len(lp.pos - tr.o, dist);
                             if (dot(fn, ldir) > 0.0 && lp.front) {
                                 ltri = lp.tri;
                                 ldist = dist;
-                                shadow_dir = ldir;
+                                tr.d = ldir;
                                 state = ST_SHADOW; // trace the shadow ray, then scatter
                                 do_scatter = false;
                             }
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     sh.alpha = tr.hit.alpha; // still the shading point's: shadow traversals leave them alone
                     sh.beta = tr.hit.beta;
                     sh.tri = sh_tri;
-                    const ShadeCtx c = make_ctx<FEAT, PAD>(S, pos, rd, sh);
+                    const ShadeCtx c = make_ctx<FEAT, PAD>(S, tr.o, rd, sh);
                     const DMaterial& m = MATERIAL(c.material);
                     d3 att, wi;
                     if (mat_scatter<FEAT>(S, m, rd, c.f, c.uv, rng, att, wi, have_fr, fr_seen)) {
@@ -399,8 +400,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                             PST_ST(S_BETA, beta);
                             // a zero throughput (Phong bad sample) contributes exactly 0 from here on
                             if (!(beta.x == 0. && beta.y == 0. && beta.z == 0.)) {
-                                next_o = pos;
-                                next_d = wi;
+                                tr.d = wi;
                                 prev_skip = m.skip_light_sampling != 0;
                                 first = false;
                                 end_sample = false;
@@ -481,8 +481,8 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     fx += rng.next() - 0.5;
                 }
                 const d3 ps = ld3(C.pixel00) + fx * ld3(C.du) + fy * ld3(C.dv);
-                next_o = ld3(C.center);
-                next_d = ps - next_o;
+                tr.o = ld3(C.center);
+                tr.d = ps - tr.o;
                 PST_ST(S_BETA, mk3(1, 1, 1));
                 depth = P.max_depth;
                 first = true;
@@ -502,8 +502,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 const bool sh_ray = state == ST_SHADOW;
                 n_closest += sh_ray ? 0u : 1u;
                 n_shadow += sh_ray ? 1u : 0u;
-                tr.init(S, sh_ray ? pos : next_o, sh_ray ? shadow_dir : next_d, sh_ray ? 0.001 : 0.0001,
-                        sh_ray ? ldist - 0.001 : PRT_INF);
+                tr.start(S, sh_ray ? 0.001 : 0.0001, sh_ray ? ldist - 0.001 : PRT_INF);
             }
         }
         PROF_MARK(4); // traversal set-up
