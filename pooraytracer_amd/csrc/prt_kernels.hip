@@ -185,25 +185,24 @@ enum : int { ST_FETCH = 0, ST_NEW_SAMPLE = 1, ST_CLOSEST = 2, ST_SHADOW = 3, ST_
 // Shading context of a hit, rebuilt from (incoming ray, HitInfo): HitRecord of Triangle::Hit
 // (Triangle.cpp:76-80,111) — position = ray(t), face-forwarded normal, tangent, uv.
 struct ShadeCtx {
-    d3 pos;
     Frame f;
     d2 uv;
     int32_t material;
 };
+// `rd` = the direction the hit was reached along, (alpha, beta, tri) = the hit (read in place: no HitInfo copy)
 template <int FEAT, bool PAD>
-PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 ro, d3 rd, const HitInfo& h) {
+PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 rd, double alpha, double beta, int32_t tri) {
     ShadeCtx c;
-    const DTriShade* sh = S.shade + h.tri;
-    const DTri* T = tri_at<PAD>(S, (uint32_t)h.tri);
+    const DTriShade* sh = S.shade + tri;
+    const DTri* T = tri_at<PAD>(S, (uint32_t)tri);
     const d3 gn = mk3(T->n[0], T->n[1], T->n[2]);
     const bool front = dot(rd, gn) < 0.;
     c.f.n = front ? gn : -gn;
     c.f.t = ld3(sh->tangent);
-    c.pos = ro + rd * h.t;
     if (FEAT & PRT_FEAT_TEX) { // texture coordinates are only read by image-textured materials
-        const double w0 = 1. - h.alpha - h.beta;
-        c.uv.x = w0 * sh->uv0[0] + h.alpha * sh->uv1[0] + h.beta * sh->uv2[0];
-        c.uv.y = w0 * sh->uv0[1] + h.alpha * sh->uv1[1] + h.beta * sh->uv2[1];
+        const double w0 = 1. - alpha - beta;
+        c.uv.x = w0 * sh->uv0[0] + alpha * sh->uv1[0] + beta * sh->uv2[0];
+        c.uv.y = w0 * sh->uv0[1] + alpha * sh->uv1[1] + beta * sh->uv2[1];
     } else {
         c.uv.x = c.uv.y = 0.0;
     }
@@ -296,29 +295,27 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
             // origin = shading point, direction towards the light; continuation: same origin, scattered direction; new
             // sample: the camera ray) — no staging copies, no selects at the traversal set-up.  After a closest hit has
             // been consumed tr.o IS the shading point.
-            HitInfo sh;
             bool have_fr = false;
             d3 fr_seen = mk3(0, 0, 0);
             if (state == ST_CLOSEST) {
-                const HitInfo h = tr.hit;
-                if (h.tri < 0) {
+                if (tr.hit.tri < 0) {
                     // miss: background for the camera ray (Camera.cpp:127); with bSampleLights a bounce miss adds 0 (:187)
                     if (first || !P.sample_lights) ADD_RADIANCE(ld3(P.background));
                     end_sample = true;
                 } else {
-                    const DMaterial& m = MATERIAL(S.shade[h.tri].material);
+                    const DMaterial& m = MATERIAL(S.shade[tr.hit.tri].material);
                     if (m.has_emission) {
                         // Camera.cpp:129-132; via a bounce only after SkipLightSampling materials (:191-195)
                         if (first || !P.sample_lights || prev_skip) ADD_RADIANCE(ld3(m.emission));
                         end_sample = true;
                     } else {
                         rd = tr.d;
-                        sh_tri = h.tri;
-                        tr.o = tr.o + tr.d * h.t; // record.position = ray(t): from here on the origin of whatever comes next
+                        sh_tri = tr.hit.tri;
+                        tr.o = tr.o + tr.d * tr.hit.t; // record.position = ray(t): from here on the origin of whatever comes next
                         do_scatter = true;
                         if (P.sample_lights && S.n_lights > 0 && !m.skip_light_sampling) {
                             // next-event estimation, Camera.cpp:137-155: pick the light point now (4 draws)
-                            const d3 gn = ld3(tri_at<PAD>(S, (uint32_t)h.tri)->n);
+                            const d3 gn = ld3(tri_at<PAD>(S, (uint32_t)sh_tri)->n);
                             const d3 fn = dot(rd, gn) < 0. ? gn : -gn;
                             const LightPick lp = sample_lights<LLDS>(S, tr.o, rng, lds_lights, P.light_lds, lds_ltris, P.ltri_lds);
                             double dist;
@@ -335,18 +332,14 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 }
             } else if (state == ST_SHADOW) {
                 // ---- shadow ray returned: visibility = closest hit no nearer than dist - 1e-3 (Camera.cpp:152-155)
-                const d3 to = tr.o, td = tr.d;
                 const double dist = ldist;
                 // The shadow ray was traced over [0.001, dist - 0.001] only: the reference's test
                 // `dist - |ps - pNearest| < 0.001` on the closest hit of [0.001, DBL_MAX) (|direction| = 1, so the distance
                 // IS t) fails exactly when some triangle is hit inside that interval; an escaping ray counts as unoccluded (B9)
                 const bool visible = tr.hit.tri < 0;
                 if (visible) {
-                    sh.t = 0.0;
-                    sh.alpha = tr.hit.alpha; // still the shading point's: shadow traversals leave them alone
-                    sh.beta = tr.hit.beta;
-                    sh.tri = sh_tri;
-                    const ShadeCtx c = make_ctx<FEAT, PAD>(S, to, rd, sh);
+                    // the barycentrics are still the shading point's: shadow traversals leave them alone
+                    const ShadeCtx c = make_ctx<FEAT, PAD>(S, rd, tr.hit.alpha, tr.hit.beta, sh_tri);
                     const DMaterial& m = MATERIAL(c.material);
                     d3 ln0;
                     double pdf;
@@ -358,11 +351,11 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                         const DLightTri* lt = S.light_tris + ltri;
                         ln0 = ld3(lt->n); pdf = lt->pdf; lmat = lt->material;   // Triangle.cpp:92, BVH.cpp:91,66
                     }
-                    // SetFaceNormal(Ray(origin, p - origin), normal) (Triangle.cpp:89-90); p - origin = td * dist
-                    const d3 ln = dot(td, ln0) < 0. ? ln0 : -ln0;
+                    // SetFaceNormal(Ray(origin, p - origin), normal) (Triangle.cpp:89-90); p - origin = tr.d * dist
+                    const d3 ln = dot(tr.d, ln0) < 0. ? ln0 : -ln0;
                     const d3 emission = ld3(MATERIAL(lmat).emission);
                     const d3 wo = world_to_local(-rd, c.f);
-                    const d3 lwi = world_to_local(td, c.f);
+                    const d3 lwi = world_to_local(tr.d, c.f);
                     const d3 fr = mat_eval<FEAT>(S, m, lwi, wo, c.uv, rng);
                     if (FEAT & PRT_FEAT_TEX) {
                         have_fr = m.type == 0; // Lambertian: Eval returned albedo / pi, which Scatter needs again
@@ -372,7 +365,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     // cosThetaB = dot(WorldToLocal(lightNormal), -wi) (Camera.cpp:166-170): the shading frame is
                     // orthonormal (tangent in the triangle's plane, bitangent = t x n), so the local dot product IS the
                     // world one — three multiplies instead of a third change of basis; differs by rounding only
-                    const double cosTB = -dot(ln, td);
+                    const double cosTB = -dot(ln, tr.d);
                     // Camera.cpp:172: emission*fr*cosT*cosTB/dist^2/pdf, the scalar factor folded into one division
                     const d3 direct = (emission * fr) * fast_div(cosT * cosTB, (dist * dist) * pdf);
                     ADD_RADIANCE(direct);
@@ -386,11 +379,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 // ---- Russian roulette + Scatter, Camera.cpp:176-202
                 end_sample = true;
                 if (rng.next() < P.rr) {
-                    sh.t = 0.0;
-                    sh.alpha = tr.hit.alpha; // still the shading point's: shadow traversals leave them alone
-                    sh.beta = tr.hit.beta;
-                    sh.tri = sh_tri;
-                    const ShadeCtx c = make_ctx<FEAT, PAD>(S, tr.o, rd, sh);
+                    const ShadeCtx c = make_ctx<FEAT, PAD>(S, rd, tr.hit.alpha, tr.hit.beta, sh_tri);
                     const DMaterial& m = MATERIAL(c.material);
                     d3 att, wi;
                     if (mat_scatter<FEAT>(S, m, rd, c.f, c.uv, rng, att, wi, have_fr, fr_seen)) {
