@@ -691,10 +691,10 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.rr = p->russian_roulette;
     P.inv_rr = 1.0 / p->russian_roulette;
     // wave scheduling thresholds (developer overrides through the environment for sweeps)
-    // measured optima at the BASELINE spp with 4-wide nodes (flat within 2 %): lean 24 / 48 / 16, textured 20 / 40 / 12, others 20 / 32 / 12
-    P.keep = s->feat == 0 ? 24 : 20;
-    P.leaf_batch = s->feat == 0 ? 48 : s->feat == 1 ? 40 : 32;
-    P.inner_min = s->feat == 0 ? 16 : 12;
+    // measured optima at the BASELINE spp with 4-wide nodes (flat within 2 %): lean 28 / 48 / 20, others 20 / 40 / 12
+    P.keep = s->feat == 0 ? 28 : 20;
+    P.leaf_batch = s->feat == 0 ? 48 : 40;
+    P.inner_min = s->feat == 0 ? 20 : 12;
     if (const char* e = std::getenv("PRT_TUNE_KEEP")) P.keep = std::atoi(e);
     if (const char* e = std::getenv("PRT_TUNE_LEAF_BATCH")) P.leaf_batch = std::atoi(e);
     if (const char* e = std::getenv("PRT_TUNE_INNER_MIN")) P.inner_min = std::atoi(e);
