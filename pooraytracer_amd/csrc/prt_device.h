@@ -22,6 +22,9 @@
 #ifndef PRT_BOX_ROTATE
 #define PRT_BOX_ROTATE (PRT_BVH_WIDTH == 4) // 4-wide nodes: packed ranges rotated by the ray's direction sign instead of min/max per axis
 #endif
+#ifndef PRT_BOX_PK
+#define PRT_BOX_PK 1 // K3 permutations other than the lean one: the two plane parameters of an axis through one v_pk_fma_f32
+#endif
 #ifndef PRT_LEAF_BATCH
 #define PRT_LEAF_BATCH 32 // parked lanes that trigger a leaf round
 #endif
@@ -272,7 +275,7 @@ PRT_DEV SlabAxis slab_axis(double o, double d, float B, float g0, float gs) {
 // cull); every accept/reject of a hit is the fp64 triangle test.  `any_hit`: traversal stops at the first accepted
 // triangle (K3's shadow rays, traced over [0.001, dist - 0.001]: anything in there is an occluder);
 // -inf for closest-hit.  The stack lives in LDS, lane-strided (`stk` = this lane's column, stride 64).
-template <bool PAD>
+template <bool PAD, bool PK = false>
 struct Trav {
     d3 o, d;
     double tmin; // K1 only: K3 derives it (and the any-hit flag) from the kind of ray, see test_leaf
@@ -320,9 +323,22 @@ struct Trav {
         x = __builtin_amdgcn_alignbit(x, x, ax.rot);
         y = __builtin_amdgcn_alignbit(y, y, ay.rot);
         z = __builtin_amdgcn_alignbit(z, z, az.rot);
-        const float nx = fmaf((float)(x & 0xffffu), ax.idq, ax.c_lo), fx = fmaf((float)(x >> 16), ax.idq, ax.c_hi);
-        const float ny = fmaf((float)(y & 0xffffu), ay.idq, ay.c_lo), fy = fmaf((float)(y >> 16), ay.idq, ay.c_hi);
-        const float nz = fmaf((float)(z & 0xffffu), az.idq, az.c_lo), fz = fmaf((float)(z >> 16), az.idq, az.c_hi);
+        float nx, fx, ny, fy, nz, fz;
+        if (PK) {
+        // entry and exit plane of an axis in one packed FMA (v_pk_fma_f32: two fp32 FMAs per instruction, 12 instead
+        // of 24 per node visit).  Costs three registers (the splat of each axis's 1/d): measured bathroom2 +1.6 %,
+        // veach-mis +0.9 %, but cornell -1.5 % (the lean kernel sits exactly at its 168-register budget and spills 4)
+        // and K1 -1 % — so K3 uses it for every permutation except the lean one.
+        typedef float f2_ __attribute__((ext_vector_type(2)));
+        const f2_ tx = __builtin_elementwise_fma(f2_{(float)(x & 0xffffu), (float)(x >> 16)}, f2_{ax.idq, ax.idq}, f2_{ax.c_lo, ax.c_hi});
+        const f2_ ty = __builtin_elementwise_fma(f2_{(float)(y & 0xffffu), (float)(y >> 16)}, f2_{ay.idq, ay.idq}, f2_{ay.c_lo, ay.c_hi});
+        const f2_ tz = __builtin_elementwise_fma(f2_{(float)(z & 0xffffu), (float)(z >> 16)}, f2_{az.idq, az.idq}, f2_{az.c_lo, az.c_hi});
+        nx = tx.x, fx = tx.y, ny = ty.x, fy = ty.y, nz = tz.x, fz = tz.y;
+        } else {
+        nx = fmaf((float)(x & 0xffffu), ax.idq, ax.c_lo), fx = fmaf((float)(x >> 16), ax.idq, ax.c_hi);
+        ny = fmaf((float)(y & 0xffffu), ay.idq, ay.c_lo), fy = fmaf((float)(y >> 16), ay.idq, ay.c_hi);
+        nz = fmaf((float)(z & 0xffffu), az.idq, az.c_lo), fz = fmaf((float)(z >> 16), az.idq, az.c_hi);
+        }
         n = fmaxf(fmaxf(fmaxf(nx, ny), nz), tminf);
         f = fminf(fminf(fminf(fx, fy), fz), tbestf);
         return;
@@ -696,7 +712,54 @@ PRT_DEV double sqr(double v) { return v * v; }
 // result is within ~1e-14 relative of pow() — far inside the 1e-9 parity tolerance — at a third of the
 // instructions and registers of the fp64 library pow.  x = 0 -> 0, x < 0 -> NaN (every caller then
 // takes its 'pdf <= 0 / lobe <= 0' branch exactly as with pow's negative/NaN result).
+#ifndef PRT_SLIM_POW
+#define PRT_SLIM_POW 1
+#endif
+#if PRT_SLIM_POW
+// Written out (fdlibm's log and a degree-13 exp on the reduced argument, both < 2 ulp) instead of calling the library
+// exp and log: a third of their instructions and, above all, ~25 fewer live registers at the Phong lobe — the
+// difference between 2 and 3 resident waves per SIMD for the Phong permutation.  x is a positive normal number or 0
+// wherever this is used (cosines of lobe angles, uniform draws >= 2^-31), the product y*log(x) is <= ~0.
+PRT_DEV double pow_pos(double x, double y) {
+    // log(x): x = m * 2^k with m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f), log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2)))
+    double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
+    int k = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? 2.0 * m : m;
+    k = lo ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = fast_div(f, 2.0 + f);
+    const double z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    const double lg = dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + (t1 + t2), dk * 1.90821492927058770002e-10)) - f);
+    // exp(t): t = n ln2 + r, |r| <= ln2 / 2
+    const double t = fmax(y * lg, -1000.0);
+    const double n = rint(t * 1.44269504088896338700e+00);
+    double r = fma(n, -6.93147180369123816490e-01, t);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;                    // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);                   // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);
+    p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 1.984126984126984e-04);
+    p = fma(p, r, 1.388888888888889e-03);
+    p = fma(p, r, 8.333333333333333e-03);
+    p = fma(p, r, 4.1666666666666664e-02);
+    p = fma(p, r, 1.6666666666666666e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    const double e = __builtin_amdgcn_ldexp(p, (int)n);
+    return x > 0.0 ? e : 0.0;
+}
+#else
 PRT_DEV double pow_pos(double x, double y) { return exp(y * log(x)); }
+#endif
 PRT_DEV double fr_complex(double cosTheta_i, Cx eta) { // MaterialUtils.h:100-111
     cosTheta_i = clampd(cosTheta_i, 0, 1);
     double sin2Theta_i = 1 - sqr(cosTheta_i);

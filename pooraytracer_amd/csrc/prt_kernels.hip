@@ -277,7 +277,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     Rng rng;
     rng.s = 0;
     const double inv_spp = 1.0 / P.spp; // pixelSamplesScale, Camera.cpp:83
-    Trav<PAD> tr;
+    Trav<PAD, PRT_BOX_PK && FEAT != 0> tr;
     tr.init(S, mk3(0, 0, 0), rd, 0.0, 0.0);
     tr.hit.alpha = tr.hit.beta = 0.0; // init() leaves the barycentrics alone (they survive shadow traversals)
     tr.active = false;
