@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 2
+#define PRT_ABI_VERSION 3
 
 /* error codes */
 #define PRT_OK 0
@@ -111,6 +111,11 @@ typedef struct PrtCamera {
 } PrtCamera;
 
 #define PRT_PRECISION_F64 0 /* reference arithmetic (glm::dvec3 everywhere) */
+/* fp32 fast mode: the same kernels with every real number a float (48-byte triangle records, hardware rcp / rsq / sqrt).
+ * Same random streams, same tree; results agree with PRT_PRECISION_F64 within the second tolerance tier (hits
+ * |dt|/t <= 1e-5, images statistically: knife-edge branches differ), not to 1e-9.  The float tables are derived from
+ * the resident fp64 ones on the first call that asks for them (that call is synchronous). */
+#define PRT_PRECISION_F32 1
 
 typedef struct PrtRenderParams {
     int32_t spp;           /* Camera::samplesPerPixel */
@@ -215,6 +220,9 @@ int prt_trace_closest(PrtScene* scene, const PrtRay* rays, size_t n, PrtHit* hit
 /* K1 on device-resident buffers (d_rays/d_hits are device pointers); stream may be NULL. */
 int prt_trace_closest_device(PrtScene* scene, const void* d_rays, size_t n, void* d_hits,
                              int count_work, void* hip_stream);
+/* Same with a PRT_PRECISION_* choice (rays and hits stay fp64 records at the boundary). */
+int prt_trace_closest_device_prec(PrtScene* scene, const void* d_rays, size_t n, void* d_hits,
+                                  int count_work, int precision, void* hip_stream);
 
 /* NEE point selection for (pixel, sample) keys 0..n-1 of `seed` from given origins (test hook). */
 int prt_sample_lights(PrtScene* scene, const double* origins, size_t n, uint64_t seed,

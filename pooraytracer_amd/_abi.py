@@ -5,7 +5,8 @@ tests/test_abi.py checks sizes and that every declared symbol is exported.
 """
 import ctypes as C
 
-PRT_ABI_VERSION = 2
+PRT_ABI_VERSION = 3
+PRECISION_F64, PRECISION_F32 = 0, 1
 
 PRT_OK = 0
 PRT_E_INVALID = -1
@@ -185,6 +186,7 @@ EXPORTS = [
     "prt_scene_light_order",
     "prt_trace_closest",
     "prt_trace_closest_device",
+    "prt_trace_closest_device_prec",
     "prt_sample_lights",
     "prt_render",
     "prt_render_device",

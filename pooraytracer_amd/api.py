@@ -55,6 +55,7 @@ def load():
     L.prt_scene_light_order.argtypes = [vp, vp, u64]
     L.prt_trace_closest.argtypes = [vp, vp, sz, vp, i32]
     L.prt_trace_closest_device.argtypes = [vp, vp, sz, vp, i32, vp]
+    L.prt_trace_closest_device_prec.argtypes = [vp, vp, sz, vp, i32, i32, vp]
     L.prt_sample_lights.argtypes = [vp, vp, sz, u64, vp]
     L.prt_render.argtypes = [vp, vp, vp, vp, vp]
     L.prt_render_device.argtypes = [vp, vp, vp, vp, vp, i32, vp]
@@ -141,8 +142,9 @@ class Scene:
         _check(load().prt_trace_closest(self._h, rays.ctypes.data, rays.shape[0], hits.ctypes.data, int(count_work)))
         return hits
 
-    def trace_closest_device(self, d_rays_ptr, n, d_hits_ptr, count_work=False, stream=None):
-        _check(load().prt_trace_closest_device(self._h, d_rays_ptr, n, d_hits_ptr, int(count_work), stream))
+    def trace_closest_device(self, d_rays_ptr, n, d_hits_ptr, count_work=False, stream=None, precision=0):
+        """K1 on device buffers; precision = _abi.PRECISION_F64 (default) or PRECISION_F32 (fp32 fast mode)."""
+        _check(load().prt_trace_closest_device_prec(self._h, d_rays_ptr, n, d_hits_ptr, int(count_work), int(precision), stream))
 
     def sample_lights(self, origins, seed=1):
         origins = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)

@@ -286,6 +286,40 @@ bool validate_nodes(const DNode* nodes, size_t n_nodes, size_t n_tris, std::stri
     return true;
 }
 
+// Stack entries a traversal of this tree can need at most: a visit of a node with k children pushes up to k - 1 of
+// them and descends into the remaining one, so need(node) = (k - 1) + max over inner children of need(child).  The
+// builders bound this to PRT_STACK_DEPTH; most trees need far less, and a launch sizes its LDS stacks from it.
+int tree_stack_need(const DNode* nodes, size_t n_nodes) {
+    if (n_nodes == 0) return 0;
+    std::vector<int> need(n_nodes, 0);
+    std::vector<std::pair<uint32_t, int>> st;
+    st.push_back({0u, 0});
+    while (!st.empty()) {
+        auto [i, phase] = st.back();
+        st.pop_back();
+        int32_t refs[4];
+        int nr = 0;
+#if PRT_BVH_WIDTH == 4
+        for (int c = 0; c < 4; ++c)
+            if (nodes[i].ref[c] != (int32_t)0x80000000) refs[nr++] = nodes[i].ref[c];
+#else
+        refs[nr++] = nodes[i].ref0;
+        if (nodes[i].ref1 != nodes[i].ref0) refs[nr++] = nodes[i].ref1;
+#endif
+        if (phase == 0) {
+            st.push_back({i, 1});
+            for (int c = 0; c < nr; ++c)
+                if (refs[c] >= 0 && (size_t)refs[c] < n_nodes) st.push_back({(uint32_t)refs[c], 0});
+        } else {
+            int worst = 0;
+            for (int c = 0; c < nr; ++c)
+                if (refs[c] >= 0 && (size_t)refs[c] < n_nodes) worst = std::max(worst, need[refs[c]]);
+            need[i] = std::max(0, nr - 1) + worst;
+        }
+    }
+    return need[0];
+}
+
 bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err) {
     out.nodes.clear();
     out.order.clear();
@@ -393,10 +427,12 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
             int budget;    // stack entries its subtree may use
             uint32_t depth;
         };
+        // Collapses the binary tree into `nodes` such that no traversal can need more than `stack_budget` entries.
+        auto collapse = [&](int stack_budget, std::vector<DNode>& nodes) -> uint32_t {
         std::vector<Open> todo;
-        out.nodes.clear();
-        out.nodes.emplace_back();
-        todo.push_back({0, 0, PRT_STACK_DEPTH, 0});
+        nodes.clear();
+        nodes.emplace_back();
+        todo.push_back({0, 0, stack_budget, 0});
         uint32_t wide_depth = 0;
         const bool single = n == 1; // the one-triangle root lists its leaf twice: keep one copy
         while (!todo.empty()) {
@@ -439,15 +475,23 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
                 d.bz[i] = (uint32_t)qlo(kids[i].lo[2], 2) | ((uint32_t)qhi(kids[i].hi[2], 2) << 16);
                 if (kids[i].ref < 0) d.ref[i] = kids[i].ref;
                 else {
-                    d.ref[i] = (int32_t)out.nodes.size();
-                    out.nodes.emplace_back();
+                    d.ref[i] = (int32_t)nodes.size();
+                    nodes.emplace_back();
                 }
             }
             for (int i = nk - 1; i >= 0; --i) // depth-first, first child next
                 if (kids[i].ref >= 0) todo.push_back({kids[i].ref, (uint32_t)d.ref[i], o.budget - (nk - 1), o.depth + 1});
-            out.nodes[o.slot] = d;
+            nodes[o.slot] = d;
         }
-        out.depth = wide_depth + 1;
+        return wide_depth + 1;
+        };
+        out.depth = collapse(PRT_STACK_DEPTH, out.nodes);
+        // A second collapse of the same binary tree (same leaves, same triangle order) for launches that want small
+        // LDS stacks — the fp32 render kernels fit a fourth block per CU when a lane's stack is 32 entries — kept
+        // only when the first one can need more than that.
+        out.stack_need = tree_stack_need(out.nodes.data(), out.nodes.size());
+        out.nodes_shallow.clear();
+        if (out.stack_need > PRT_STACK_SHALLOW) collapse(PRT_STACK_SHALLOW, out.nodes_shallow);
     }
 #else
     for (size_t i = 0; i < fn.size(); ++i) {

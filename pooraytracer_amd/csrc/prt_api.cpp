@@ -16,9 +16,10 @@
 #include "prt_host.h"
 
 namespace prt {
-int render_blocks_per_cu(bool count, int feat, size_t dyn_lds);
+int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth);
 int render_permutation(int feat);
-int render_lds_budget(int feat);
+int render_lds_budget(int feat, int stack_depth);
+size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds);
 void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hits, DCounters* d_ctr, bool count, int n_cu,
                   hipStream_t st);
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
@@ -37,6 +38,21 @@ void launch_texture_value(const DScene& S, int texture, const double* uv, size_t
 void launch_gather_tris(const DTri* tri_in, const DTriShade* shade_in, const uint32_t* order, uint32_t n, void* tri_out,
                         uint32_t tri_out_stride, DTriShade* shade_out, hipStream_t st);
 } // namespace prt
+
+// fp32 fast mode (prt_kernels_f32.hip): K1 and K3 on float records derived from the resident fp64 ones
+namespace prt32 {
+typedef DSceneT<float> Scene32;
+int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth);
+int render_lds_budget(int feat, int stack_depth);
+size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds);
+void launch_trace(const Scene32& S, const PrtRay* d_rays, size_t n, PrtHit* d_hits, DCounters* d_ctr, bool count, int n_cu,
+                  hipStream_t st);
+void launch_render(const Scene32& S, const DCameraT<float>& C, const DRenderParamsT<float>& P, double* d_partial,
+                   DCounters* d_ctr, bool count, int feat, unsigned grid, hipStream_t st);
+void launch_convert_tris(const void* in, uint32_t in_stride, uint32_t n, void* out, uint32_t out_stride, hipStream_t st);
+void launch_convert_shade(const DTriShadeT<double>* in, uint32_t n, DTriShadeT<float>* out, hipStream_t st);
+void launch_convert_reals(const double* in, size_t n, float* out, hipStream_t st);
+} // namespace prt32
 
 namespace {
 thread_local std::string g_err;
@@ -76,6 +92,12 @@ struct PrtScene {
     int light_lds = 0, mat_lds = 0; // light-tree nodes / materials staged in LDS by K3 (both 0 = the kernels without LDS tables)
     int feat = 0; // material features of the scene (1 textures, 2 Phong, 4 CookTorrance) -> K3 permutation
     DScene d{};
+    // fp32 fast mode: float copies of the tables, made on the first PRT_PRECISION_F32 call (ensure_f32)
+    DSceneT<float> d32{};
+    bool f32_ready = false;
+    int blocks_per_cu32[2] = {0, 0};
+    int ltri_lds32 = 0, light_lds32 = 0, mat_lds32 = 0; // table sizes of the fp32 kernels (their own LDS budget)
+    int stack_depth32 = PRT_STACK_DEPTH;                // LDS stack entries per lane of the fp32 render kernels
     std::vector<void*> allocs;
     // Per-call device state, double-buffered: consecutive calls alternate slots, so a caller that
     // alternates two streams (and two framebuffers) can have frame k+1 filling the GPU while the last
@@ -127,8 +149,14 @@ struct PrtScene {
             q = CallSlot();
         }
         device = -1;
+        f32_ready = false;
     }
 };
+
+template <typename T, typename U>
+static void conv_arr(T* o, const U* a, int n) {
+    for (int i = 0; i < n; ++i) o[i] = (T)a[i];
+}
 
 extern "C" {
 
@@ -277,6 +305,23 @@ int prt_scene_light_order(const PrtScene* s, int32_t* prims, uint64_t cap) {
 }
 
 static int upload_impl(PrtScene* s, int device);
+
+// How much of the material table, the light triangles and the light tree a render kernel stages in LDS, given the
+// bytes a block may spend on them (record sizes differ between the fp64 and the fp32 kernels).
+static void size_tables(const PrtScene* s, int budget, size_t mat_bytes, size_t ltri_bytes, size_t lnode_bytes, int* mat, int* ltri, int* light) {
+    *mat = *ltri = *light = 0;
+    const bool off = std::getenv("PRT_TUNE_NO_LDS") && std::atoi(std::getenv("PRT_TUNE_NO_LDS"));
+    if (off || s->mats.empty() || s->mats.size() * mat_bytes > 8192 || (int)(s->mats.size() * mat_bytes) > budget) return;
+    *mat = (int)s->mats.size();
+    budget -= *mat * (int)mat_bytes;
+    if (!s->lights.tris.empty() && s->lights.tris.size() <= 32 && (int)(s->lights.tris.size() * ltri_bytes) <= budget) {
+        *ltri = (int)s->lights.tris.size();
+        budget -= *ltri * (int)ltri_bytes;
+    }
+    *light = (int)std::min<size_t>(s->lights.nodes.size(), (size_t)(std::max(budget, 0) / (int)lnode_bytes));
+    if (const char* e = std::getenv("PRT_TUNE_LIGHT_LDS")) *light = std::min(*light, std::max(0, std::atoi(e)));
+    if (const char* e = std::getenv("PRT_TUNE_LTRI_LDS")) if (!std::atoi(e)) *ltri = 0;
+}
 
 // Either the whole scene is resident afterwards, or nothing is: a failure anywhere (allocation, copy, device build)
 // releases what was uploaded so far and leaves the scene in the not-uploaded state (device = -1), so that no later
@@ -454,27 +499,12 @@ static int upload_impl(PrtScene* s, int device) {
     // value per byte: the material table (must fit, <= 8 KB), all light triangles if there are at most 32, then
     // as many top levels of the light tree (breadth-first numbering) as the remaining budget holds.
     // Measured: materials cornell +2.5 %, bathroom2 +3 %, veach-mis +2 %; light tree veach-mis +5 %.
-    {
-        int budget = prt::render_lds_budget(s->feat);
-        s->mat_lds = s->ltri_lds = s->light_lds = 0;
-        const bool off = std::getenv("PRT_TUNE_NO_LDS") && std::atoi(std::getenv("PRT_TUNE_NO_LDS"));
-        if (!off && !s->mats.empty() && s->mats.size() * sizeof(DMaterial) <= 8192) {
-            s->mat_lds = (int)s->mats.size();
-            budget -= s->mat_lds * (int)sizeof(DMaterial);
-            if (!s->lights.tris.empty() && s->lights.tris.size() <= 32) {
-                s->ltri_lds = (int)s->lights.tris.size();
-                budget -= s->ltri_lds * (int)sizeof(DLightTri);
-            }
-            s->light_lds = (int)std::min<size_t>(s->lights.nodes.size(), (size_t)(budget / (int)sizeof(DLightNode)));
-            if (const char* e = std::getenv("PRT_TUNE_LIGHT_LDS")) s->light_lds = std::min(s->light_lds, std::max(0, std::atoi(e)));
-            if (const char* e = std::getenv("PRT_TUNE_LTRI_LDS")) if (!std::atoi(e)) s->ltri_lds = 0;
-        }
-    }
+    size_tables(s, prt::render_lds_budget(s->feat, PRT_STACK_DEPTH), sizeof(DMaterial), sizeof(DLightTri), sizeof(DLightNode),
+                &s->mat_lds, &s->ltri_lds, &s->light_lds);
     static_assert(sizeof(DLightNode) == 16 && sizeof(DLightTri) % 16 == 0, "LDS staging copies 16-byte pieces");
-    const size_t dyn_lds = (size_t)s->light_lds * sizeof(DLightNode) + (size_t)s->mat_lds * sizeof(DMaterial) +
-                           (size_t)s->ltri_lds * sizeof(DLightTri);
-    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat, dyn_lds);
-    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, dyn_lds);
+    const size_t tables = prt::render_table_bytes(s->light_lds, s->mat_lds, s->ltri_lds);
+    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat, tables, PRT_STACK_DEPTH);
+    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, tables, PRT_STACK_DEPTH);
     return PRT_OK;
 }
 
@@ -513,6 +543,113 @@ int prt_scene_update_vertices(PrtScene* s, const double* vertices, const double*
     return PRT_OK;
 }
 
+// fp32 fast mode: the float tables are derived from the resident fp64 ones the first time they are asked for
+// (synchronous; the scene then holds both).  Triangle and shading records and texels are converted on the device —
+// they already are in BVH leaf order there, whichever builder made the tree — the small tables on the host.
+static int ensure_f32(PrtScene* s) {
+    if (s->f32_ready) return PRT_OK;
+    const DScene& d = s->d;
+    DSceneT<float>& f = s->d32;
+    std::memset(&f, 0, sizeof(f));
+    const size_t n = d.n_tris;
+    const uint32_t stride = d.tri_stride == sizeof(DTriT<double>) ? (uint32_t)sizeof(DTriT<float>) : PRT_TRI_PAD_STRIDE(float);
+    void *t = nullptr, *sh = nullptr, *tx = nullptr;
+    PRT_HIP(hipMalloc(&t, std::max<size_t>(n * (size_t)stride, 256)));
+    s->allocs.push_back(t);
+    PRT_HIP(hipMalloc(&sh, std::max<size_t>(n * sizeof(DTriShadeT<float>), 256)));
+    s->allocs.push_back(sh);
+    PRT_HIP(hipMalloc(&tx, std::max<size_t>(s->texels_lin.size() * sizeof(float), 256)));
+    s->allocs.push_back(tx);
+    prt32::launch_convert_tris(d.tris, d.tri_stride, (uint32_t)n, t, stride, nullptr);
+    prt32::launch_convert_shade(d.shade, (uint32_t)n, static_cast<DTriShadeT<float>*>(sh), nullptr);
+    prt32::launch_convert_reals(d.texels_lin, s->texels_lin.size(), static_cast<float*>(tx), nullptr);
+    PRT_HIP(hipGetLastError());
+    std::vector<DMaterialT<float>> mats(s->mats.size());
+    for (size_t i = 0; i < mats.size(); ++i) {
+        const DMaterial& a = s->mats[i];
+        DMaterialT<float>& o = mats[i];
+        std::memset(&o, 0, sizeof(o));
+        o.type = a.type; o.texture = a.texture;
+        conv_arr(o.kd, a.kd, 3); conv_arr(o.ks, a.ks, 3); conv_arr(o.emission, a.emission, 3);
+        conv_arr(o.eta, a.eta, 3); conv_arr(o.k, a.k, 3);
+        o.ns = (float)a.ns; o.pkd = (float)a.pkd; o.pks = (float)a.pks;
+        o.alpha_x = (float)a.alpha_x; o.alpha_y = (float)a.alpha_y;
+        o.has_emission = a.has_emission; o.skip_light_sampling = a.skip_light_sampling;
+        o.inv_ns1 = (float)a.inv_ns1; o.spec_scale = (float)a.spec_scale;
+    }
+    std::vector<DLightNodeT<float>> ln(s->lights.nodes.size());
+    for (size_t i = 0; i < ln.size(); ++i) {
+        std::memset(&ln[i], 0, sizeof(ln[i]));
+        ln[i].left_area = (float)s->lights.nodes[i].left_area;
+        ln[i].left = s->lights.nodes[i].left;
+        ln[i].right = s->lights.nodes[i].right;
+    }
+    std::vector<DLightTriT<float>> lt(s->lights.tris.size());
+    for (size_t i = 0; i < lt.size(); ++i) {
+        const DLightTri& a = s->lights.tris[i];
+        DLightTriT<float>& o = lt[i];
+        std::memset(&o, 0, sizeof(o));
+        conv_arr(o.v0, a.v0, 3); conv_arr(o.v1, a.v1, 3); conv_arr(o.v2, a.v2, 3); conv_arr(o.n, a.n, 3);
+        o.area = (float)a.area; o.material = a.material; o.prim = a.prim; o.pdf = (float)a.pdf;
+    }
+    int rc;
+    const int keep_fail = s->fail_upload_at;
+    s->fail_upload_at = -1;
+    if ((rc = s->up(mats, &f.materials)) || (rc = s->up(ln, &f.light_nodes)) || (rc = s->up(lt, &f.light_tris))) {
+        s->fail_upload_at = keep_fail;
+        return rc;
+    }
+    s->fail_upload_at = keep_fail;
+    PRT_HIP(hipDeviceSynchronize());
+    f.nodes = d.nodes;
+    f.tris = static_cast<const DTriT<float>*>(t);
+    f.shade = static_cast<const DTriShadeT<float>*>(sh);
+    f.textures = d.textures;
+    f.texels_lin = static_cast<const float*>(tx);
+    f.light_root = d.light_root;
+    f.n_lights = d.n_lights;
+    f.light_area = (float)d.light_area;
+    f.n_nodes = d.n_nodes;
+    f.n_tris = d.n_tris;
+    f.coord_scale = d.coord_scale;
+    for (int a = 0; a < 3; ++a) {
+        f.grid_origin[a] = d.grid_origin[a];
+        f.grid_step[a] = d.grid_step[a];
+    }
+    f.tri_stride = stride;
+    // The fp32 kernels have the registers for a fourth wave per SIMD; whether the LDS has room for a fourth block per CU
+    // is decided by the traversal stacks: 32 entries per lane (32 KB per block) leave it, the builders' bound of
+    // PRT_STACK_DEPTH does not.  Most trees need far fewer entries than that bound (tree_stack_need).
+    {
+        int need = PRT_STACK_DEPTH;
+        if (!s->bvh_info.built_on_device) {
+            need = s->bvh.stack_need;
+            if (need > PRT_STACK_SHALLOW && !s->bvh.nodes_shallow.empty()) {
+                // the same binary tree collapsed with the smaller budget (same leaf order: the records above fit both)
+                const int keep = s->fail_upload_at;
+                s->fail_upload_at = -1;
+                rc = s->up(s->bvh.nodes_shallow, &f.nodes);
+                s->fail_upload_at = keep;
+                if (rc) return rc;
+                f.n_nodes = (uint32_t)s->bvh.nodes_shallow.size();
+                need = PRT_STACK_SHALLOW;
+            }
+        } else {
+            std::vector<DNode> hn(d.n_nodes);
+            PRT_HIP(hipMemcpy(hn.data(), d.nodes, (size_t)d.n_nodes * sizeof(DNode), hipMemcpyDeviceToHost));
+            need = prt::tree_stack_need(hn.data(), hn.size());
+        }
+        s->stack_depth32 = need <= PRT_STACK_SHALLOW ? PRT_STACK_SHALLOW : PRT_STACK_DEPTH;
+    }
+    size_tables(s, prt32::render_lds_budget(s->feat, s->stack_depth32), sizeof(DMaterialT<float>), sizeof(DLightTriT<float>),
+                sizeof(DLightNodeT<float>), &s->mat_lds32, &s->ltri_lds32, &s->light_lds32);
+    const size_t tables = prt32::render_table_bytes(s->light_lds32, s->mat_lds32, s->ltri_lds32);
+    s->blocks_per_cu32[0] = prt32::render_blocks_per_cu(false, s->feat, tables, s->stack_depth32);
+    s->blocks_per_cu32[1] = prt32::render_blocks_per_cu(true, s->feat, tables, s->stack_depth32);
+    s->f32_ready = true;
+    return PRT_OK;
+}
+
 static int require_uploaded(PrtScene* s, const char* who) {
     if (!s) return fail(PRT_E_INVALID, std::string(who) + ": null scene");
     if (s->device < 0) return fail(PRT_E_NO_DEVICE, std::string(who) + ": scene is not uploaded to a HIP device (no CPU path exists)");
@@ -521,17 +658,28 @@ static int require_uploaded(PrtScene* s, const char* who) {
 }
 
 int prt_trace_closest_device(PrtScene* s, const void* d_rays, size_t n, void* d_hits, int count_work, void* stream) {
+    return prt_trace_closest_device_prec(s, d_rays, n, d_hits, count_work, PRT_PRECISION_F64, stream);
+}
+
+int prt_trace_closest_device_prec(PrtScene* s, const void* d_rays, size_t n, void* d_hits, int count_work, int precision,
+                                  void* stream) {
     int rc = require_uploaded(s, "prt_trace_closest_device");
     if (rc) return rc;
     if (n && (!d_rays || !d_hits)) return fail(PRT_E_INVALID, "prt_trace_closest_device: null buffer");
+    if (precision != PRT_PRECISION_F64 && precision != PRT_PRECISION_F32) return fail(PRT_E_INVALID, "prt_trace_closest_device: unsupported precision");
+    if (precision == PRT_PRECISION_F32 && (rc = ensure_f32(s))) return rc;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipError_t we;
     PrtScene::CallSlot& q = *s->next_slot(st, &we);
     PRT_HIP(we);
     PRT_HIP(hipMemsetAsync(q.d_ctr, 0, sizeof(DCounters), st));
     PRT_HIP(hipEventRecord(q.ev0, st));
-    prt::launch_trace(s->d, static_cast<const PrtRay*>(d_rays), n, static_cast<PrtHit*>(d_hits), q.d_ctr, count_work != 0,
-                      s->n_cu, st);
+    if (precision == PRT_PRECISION_F32)
+        prt32::launch_trace(s->d32, static_cast<const PrtRay*>(d_rays), n, static_cast<PrtHit*>(d_hits), q.d_ctr, count_work != 0,
+                            s->n_cu, st);
+    else
+        prt::launch_trace(s->d, static_cast<const PrtRay*>(d_rays), n, static_cast<PrtHit*>(d_hits), q.d_ctr, count_work != 0,
+                          s->n_cu, st);
     PRT_HIP(hipGetLastError());
     PRT_HIP(hipEventRecord(q.ev1, st));
     PRT_HIP(hipEventRecord(q.done, st));
@@ -677,7 +825,9 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     if (!cam || !p) return fail(PRT_E_INVALID, "prt_render_device: null argument");
     if (cam->width < 1 || cam->height < 1) return fail(PRT_E_INVALID, "prt_render_device: bad image size");
     if (p->spp < 1) return fail(PRT_E_INVALID, "prt_render_device: spp must be >= 1");
-    if (p->precision != PRT_PRECISION_F64) return fail(PRT_E_INVALID, "prt_render_device: unsupported precision");
+    if (p->precision != PRT_PRECISION_F64 && p->precision != PRT_PRECISION_F32) return fail(PRT_E_INVALID, "prt_render_device: unsupported precision");
+    const bool f32 = p->precision == PRT_PRECISION_F32;
+    if (f32 && (rc = ensure_f32(s))) return rc;
     if (p->nranks < 1 || p->rank < 0 || p->rank >= p->nranks) return fail(PRT_E_INVALID, "prt_render_device: bad rank/nranks");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 
@@ -713,10 +863,11 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.light_lds = s->light_lds;
     P.mat_lds = s->mat_lds;
     P.ltri_lds = s->ltri_lds;
+    P.stack_depth = PRT_STACK_DEPTH;
     P.owned_tiles = P.n_tiles > P.rank ? (P.n_tiles - P.rank + P.nranks - 1) / P.nranks : 0;
     P.items_per_chunk = (uint64_t)P.owned_tiles * tile * tile;
     const bool count = count_work != 0;
-    const int bpc = s->blocks_per_cu[count ? 1 : 0];
+    const int bpc = f32 ? s->blocks_per_cu32[count ? 1 : 0] : s->blocks_per_cu[count ? 1 : 0];
     const uint64_t lanes = (uint64_t)s->n_cu * bpc * PRT_BLOCK;
     // Work item = (pixel, chunk of samples), dealt chunk-major from PRT_ITEM_QUEUES counters (prt_types.h).
     //  * explicit sample_chunks: that many equal chunks;
@@ -794,7 +945,29 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     if (P.n_items) {
         const uint64_t want = (P.n_items + PRT_BLOCK - 1) / PRT_BLOCK;
         const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)s->n_cu * bpc));
-        prt::launch_render(s->d, C, P, q.d_partial, q.d_ctr, count, s->feat, grid, st);
+        if (f32) {
+            // the same camera and parameters rounded to float (K5 below works from the fp64 originals: it only maps pixels)
+            DCameraT<float> C32;
+            conv_arr(C32.center, C.center, 3); conv_arr(C32.pixel00, C.pixel00, 3);
+            conv_arr(C32.du, C.du, 3); conv_arr(C32.dv, C.dv, 3);
+            C32.width = C.width; C32.height = C.height;
+            DRenderParamsT<float> P32;
+            std::memset(&P32, 0, sizeof(P32));
+            P32.spp = P.spp; P32.max_depth = P.max_depth; P32.sample_lights = P.sample_lights; P32.chunks = P.chunks;
+            P32.rr = (float)P.rr; P32.inv_rr = (float)P.inv_rr;
+            conv_arr(P32.background, P.background, 3);
+            P32.seed = P.seed;
+            P32.tile = P.tile; P32.tiles_x = P.tiles_x; P32.tiles_y = P.tiles_y; P32.n_tiles = P.n_tiles;
+            P32.rank = P.rank; P32.nranks = P.nranks; P32.owned_tiles = P.owned_tiles; P32.jitter = P.jitter;
+            P32.keep = P.keep; P32.leaf_batch = P.leaf_batch; P32.inner_min = P.inner_min; P32.scramble = P.scramble;
+            P32.light_lds = s->light_lds32; P32.mat_lds = s->mat_lds32; P32.ltri_lds = s->ltri_lds32;
+            P32.stack_depth = s->stack_depth32;
+            P32.items_per_chunk = P.items_per_chunk; P32.n_items = P.n_items;
+            std::memcpy(P32.chunk_begin, P.chunk_begin, sizeof(P.chunk_begin));
+            prt32::launch_render(s->d32, C32, P32, q.d_partial, q.d_ctr, count, s->feat, grid, st);
+        } else {
+            prt::launch_render(s->d, C, P, q.d_partial, q.d_ctr, count, s->feat, grid, st);
+        }
         PRT_HIP(hipGetLastError());
     }
     PRT_HIP(hipEventRecord(q.ev1, st));

@@ -12,6 +12,16 @@
 #include "prt_types.h"
 
 #define PRT_DEV __device__ __forceinline__
+// The scalar type of everything that is a real number in the reference (glm::dvec3 arithmetic): double, or float in the
+// translation unit of the fp32 fast mode (prt_kernels_f32.hip).  RL() types a literal: a bare `2.` in an fp32
+// expression would silently promote it to fp64.
+typedef prt_real real;
+#define PRT_F32 (sizeof(prt_real) == 4)
+#define RL(x) ((real)(x))
+template <typename R> struct real4_of;
+template <> struct real4_of<double> { typedef double4 type; };
+template <> struct real4_of<float> { typedef float4 type; };
+typedef real4_of<real>::type real4;
 #define PRT_NOCUR ((int32_t)0x80000000) // Trav::cur sentinel (never a valid leaf ref: n_tris < 2^28)
 #ifndef PRT_DEFER_LEAF
 #define PRT_DEFER_LEAF 0 // speculative leaf deferral: better lane utilisation (node rounds 51%->55%) but 3-5% slower (more triangle tests, heavier leaf rounds) on MI355X
@@ -34,21 +44,21 @@
 
 // ------------------------------------------------------------------ dvec3 subset (glm semantics)
 struct d3 {
-    double x, y, z;
+    real x, y, z;
 };
 struct d2 {
-    double x, y;
+    real x, y;
 };
-PRT_DEV d3 mk3(double x, double y, double z) { return d3{x, y, z}; }
-PRT_DEV d3 ld3(const double* p) { return d3{p[0], p[1], p[2]}; }
+PRT_DEV d3 mk3(real x, real y, real z) { return d3{x, y, z}; }
+PRT_DEV d3 ld3(const real* p) { return d3{p[0], p[1], p[2]}; }
 PRT_DEV d3 operator+(d3 a, d3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 PRT_DEV d3 operator-(d3 a, d3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 PRT_DEV d3 operator-(d3 a) { return {-a.x, -a.y, -a.z}; }
 PRT_DEV d3 operator*(d3 a, d3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
-PRT_DEV d3 operator*(d3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
-PRT_DEV d3 operator*(double s, d3 a) { return {s * a.x, s * a.y, s * a.z}; }
-PRT_DEV d3 operator/(d3 a, double s); // = a * (1/s): defined below, next to the reciprocal it uses
-PRT_DEV double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+PRT_DEV d3 operator*(d3 a, real s) { return {a.x * s, a.y * s, a.z * s}; }
+PRT_DEV d3 operator*(real s, d3 a) { return {s * a.x, s * a.y, s * a.z}; }
+PRT_DEV d3 operator/(d3 a, real s); // = a * (1/s): defined below, next to the reciprocal it uses
+PRT_DEV real dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 PRT_DEV d3 cross(d3 x, d3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
 // fp64 square root / reciprocal for the shading code, where the kernels are VALU-bound: the hardware estimate
 // (v_rsq_f64 / v_rcp_f64, ~2^-23 relative) plus one coupled Newton step and one residual correction — within an ulp
@@ -93,26 +103,37 @@ PRT_DEV double fast_sqrt(double x) { return sqrt(x); }
 PRT_DEV double fast_rcp(double b) { return 1.0 / b; }
 PRT_DEV double fast_div(double a, double b) { return a / b; }
 #endif
-PRT_DEV d3 operator/(d3 a, double s) { // glm divides each component; one reciprocal and three multiplies differ by rounding only
-    const double r = fast_rcp(s);
+// fp32 fast mode: the hardware instructions themselves (v_rsq_f32 / v_sqrt_f32 / v_rcp_f32, 1 ulp) — one instruction each
+PRT_DEV float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+PRT_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+PRT_DEV float fast_rcp(float b) { return __builtin_amdgcn_rcpf(b); }
+PRT_DEV float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+// sqrt / division where the fp64 path wants the IEEE result (bit-exact light pick, triangle parameter t): exact in
+// fp64, the hardware estimate in fp32
+PRT_DEV double ieee_sqrt(double x) { return sqrt(x); }
+PRT_DEV float ieee_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+PRT_DEV double ieee_div(double a, double b) { return a / b; }
+PRT_DEV float ieee_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+PRT_DEV d3 operator/(d3 a, real s) { // glm divides each component; one reciprocal and three multiplies differ by rounding only
+    const real r = fast_rcp(s);
     return {a.x * r, a.y * r, a.z * r};
 }
-PRT_DEV double length(d3 v) { return fast_sqrt(dot(v, v)); }
+PRT_DEV real length(d3 v) { return fast_sqrt(dot(v, v)); }
 PRT_DEV d3 normalize(d3 v) { return v * fast_rsqrt(dot(v, v)); } // glm::normalize = v * inversesqrt(dot(v, v))
 // normalize(v) and length(v) from one square root — glm::normalize / glm::length up to rounding
-PRT_DEV d3 normalize_len(d3 v, double& len) {
-    const double q = dot(v, v);
-    const double inv = fast_rsqrt(q);
+PRT_DEV d3 normalize_len(d3 v, real& len) {
+    const real q = dot(v, v);
+    const real inv = fast_rsqrt(q);
     len = q * inv;
     return v * inv;
 }
 
-#define PRT_PI 3.14159265358979323846
-#define PRT_INV_PI 0.31830988618379067154
-#define PRT_INV_2PI 0.15915494309189533577
-#define PRT_PI_OVER_2 1.57079632679489661923
-#define PRT_PI_OVER_4 0.78539816339744830961
-#define PRT_INF __builtin_huge_val()
+#define PRT_PI RL(3.14159265358979323846)
+#define PRT_INV_PI RL(0.31830988618379067154)
+#define PRT_INV_2PI RL(0.15915494309189533577)
+#define PRT_PI_OVER_2 RL(1.57079632679489661923)
+#define PRT_PI_OVER_4 RL(0.78539816339744830961)
+#define PRT_INF RL(__builtin_huge_val())
 
 // ------------------------------------------------------------------ keyed counter RNG
 // Replaces the reference's global std::rand() (RandomNumberGenerator.h:16-19) by a stream keyed on
@@ -136,21 +157,22 @@ struct Rng {
     // xoroshiro64* started from the hashed key, top 31 bits: one quarter-rate 32-bit multiply per number instead of the
     // two 64-bit multiplies (eight quarter-rate instructions) of a splitmix hash per number — with the kernels VALU-bound
     // the cheaper stream is worth +4 % (measured against a trivial LCG: +5 %).  Same stream in oracle/pt_oracle.cpp.
-    PRT_DEV double next() {
+    PRT_DEV real next() {
         uint32_t s0 = (uint32_t)s, s1 = (uint32_t)(s >> 32);
         const uint32_t r = s0 * 0x9E3779BBu;
         s1 ^= s0;
         s0 = __builtin_amdgcn_alignbit(s0, s0, 6) ^ s1 ^ (s1 << 9); // rotl(s0, 26)
         s1 = __builtin_amdgcn_alignbit(s1, s1, 19);                 // rotl(s1, 13)
         s = ((uint64_t)s1 << 32) | s0;
-        return (double)(r >> 1) * (1.0 / 2147483648.0);
+        if (PRT_F32) return (real)(r >> 8) * RL(5.9604644775390625e-8); // 24 bits: every value is a float below 1
+        return (real)(r >> 1) * (RL(1.0) / RL(2147483648.0));
     }
 };
 
 // ------------------------------------------------------------------ BVH traversal
 struct HitInfo {
-    double t;      // closest accepted t (== tmax on miss)
-    double alpha, beta;
+    real t;      // closest accepted t (== tmax on miss)
+    real alpha, beta;
     int32_t tri;   // BVH-order triangle index, -1 on miss
 };
 
@@ -165,27 +187,27 @@ struct WorkCount {
 // (as a run-time value it cost the register-starved textured permutation 3 %).
 template <bool PAD>
 PRT_DEV const DTri* tri_at(const DScene& S, uint32_t i) {
-    return reinterpret_cast<const DTri*>(reinterpret_cast<const char*>(S.tris) + (size_t)i * (PAD ? 128u : (uint32_t)sizeof(DTri)));
+    return reinterpret_cast<const DTri*>(reinterpret_cast<const char*>(S.tris) + (size_t)i * (PAD ? PRT_TRI_PAD_STRIDE(real) : (uint32_t)sizeof(DTri)));
 }
 
 // Triangle::Hit + IsInterior (Triangle.cpp:54-83,100-113), inclusive interval.  PRT_TRI_FORM 0: the reference's
 // expressions; 1: the same quantities through precomputed edge functions (see DTri).
-PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, double tmin, double tmax, double& t_out, double& a_out,
-                      double& b_out, const double4* pre = nullptr, uint32_t* n_full = nullptr) {
-    const double4* q = reinterpret_cast<const double4*>(T);
-    double4 q0 = pre ? *pre : q[0], q1 = q[1]; // `pre`: the record's first 32 bytes, fetched by the caller ahead of time
+PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, real tmin, real tmax, real& t_out, real& a_out,
+                      real& b_out, const real4* pre = nullptr, uint32_t* n_full = nullptr) {
+    const real4* q = reinterpret_cast<const real4*>(T);
+    real4 q0 = pre ? *pre : q[0], q1 = q[1]; // `pre`: the record's first 32 bytes, fetched by the caller ahead of time
     d3 n = mk3(q0.x, q0.y, q0.z);
-    double denom = dot(n, d);
-    if (fabs(denom) < 1e-8) return false;
-    double t = (q0.w - dot(n, o)) / denom;
+    real denom = dot(n, d);
+    if (fabs(denom) < RL(1e-8)) return false;
+    real t = ieee_div(q0.w - dot(n, o), denom);
 #if PRT_TRI_FORM == 1
     if (!(tmin <= t && t <= tmax)) return false;
     if (n_full) ++*n_full;
     {
-        const double4 q2 = q[2];
+        const real4 q2 = q[2];
         const d3 p = o + d * t;
-        const double alpha = (p.x * q1.x + p.y * q1.y + p.z * q1.z) - q1.w;
-        const double beta = (p.x * q2.x + p.y * q2.y + p.z * q2.z) - q2.w;
+        const real alpha = (p.x * q1.x + p.y * q1.y + p.z * q1.z) - q1.w;
+        const real beta = (p.x * q2.x + p.y * q2.y + p.z * q2.z) - q2.w;
         if (alpha != alpha || beta != beta) return false;
         if ((alpha < 0) || (beta < 0) || (alpha + beta > 1)) return false;
         t_out = t;
@@ -195,14 +217,14 @@ PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, double tmin, doubl
     }
 #endif
 #if PRT_TRI_EAGER
-    double4 q2 = q[2], q3 = q[3]; // whole record requested up front: one memory latency per test instead of two
+    real4 q2 = q[2], q3 = q[3]; // whole record requested up front: one memory latency per test instead of two
     asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w)); // keeps the loads above the branch
 #endif
     if (!(tmin <= t && t <= tmax)) return false;
     if (n_full) ++*n_full;
     // record = n[3] D | w[3] v0.x | v0.yz e0.xy | e0.z e1[3]
 #if !PRT_TRI_EAGER
-    double4 q2 = q[2], q3 = q[3];
+    real4 q2 = q[2], q3 = q[3];
 #endif
     d3 w = mk3(q1.x, q1.y, q1.z);
     d3 v0 = mk3(q1.w, q2.x, q2.y);
@@ -210,8 +232,8 @@ PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, double tmin, doubl
     d3 e1 = mk3(q3.y, q3.z, q3.w);
     d3 p = o + d * t;
     d3 v0p = p - v0;
-    double alpha = dot(w, cross(v0p, e1));
-    double beta = dot(w, cross(e0, v0p));
+    real alpha = dot(w, cross(v0p, e1));
+    real beta = dot(w, cross(e0, v0p));
     if (alpha != alpha || beta != beta) return false;
     if ((alpha < 0) || (beta < 0) || (alpha + beta > 1)) return false;
     t_out = t;
@@ -221,11 +243,11 @@ PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, double tmin, doubl
 }
 
 // Conservative double -> float conversions (round-to-nearest error <= 2^-24 relative, widened by 2^-22).
-PRT_DEV float f32_up(double x) {
+PRT_DEV float f32_up(real x) {
     const float f = (float)x;
     return f + fabsf(f) * 2.4e-7f;
 }
-PRT_DEV float f32_down(double x) {
+PRT_DEV float f32_down(real x) {
     const float f = (float)x;
     return f - fabsf(f) * 2.4e-7f;
 }
@@ -243,7 +265,7 @@ struct SlabAxis {
                   // low half is always the ENTRY plane and c_lo / c_hi are the entry / exit constants
 #endif
 };
-PRT_DEV SlabAxis slab_axis(double o, double d, float B, float g0, float gs) {
+PRT_DEV SlabAxis slab_axis(real o, real d, float B, float g0, float gs) {
     SlabAxis a;
     const float df = (float)d;
     float id = __builtin_amdgcn_rcpf(df);
@@ -278,7 +300,7 @@ PRT_DEV SlabAxis slab_axis(double o, double d, float B, float g0, float gs) {
 template <bool PAD, bool PK = false>
 struct Trav {
     d3 o, d;
-    double tmin; // K1 only: K3 derives it (and the any-hit flag) from the kind of ray, see test_leaf
+    real tmin; // K1 only: K3 derives it (and the any-hit flag) from the kind of ray, see test_leaf
     HitInfo hit;
     SlabAxis ax, ay, az;
     float tminf, tbestf;
@@ -287,13 +309,13 @@ struct Trav {
     int32_t sp;
     bool active;
 
-    PRT_DEV void init(const DScene& S, d3 o_, d3 d_, double tmin_, double tmax_) {
+    PRT_DEV void init(const DScene& S, d3 o_, d3 d_, real tmin_, real tmax_) {
         o = o_;
         d = d_;
         start(S, tmin_, tmax_);
     }
     // Starts the traversal of the ray already in o / d.
-    PRT_DEV void start(const DScene& S, double tmin_, double tmax_) {
+    PRT_DEV void start(const DScene& S, real tmin_, real tmax_) {
         tmin = tmin_;
 #if PRT_NODE16
         ax = slab_axis(o.x, d.x, S.coord_scale, S.grid_origin[0], S.grid_step[0]);
@@ -515,7 +537,7 @@ struct Trav {
 
     // fp64 tests of one leaf's triangles (128-byte records); returns true when an early-out hit was accepted.
     template <bool COUNT>
-    PRT_DEV bool test_leaf(const DScene& S, int32_t ref, WorkCount& wc, double tmin_use, bool any_hit) {
+    PRT_DEV bool test_leaf(const DScene& S, int32_t ref, WorkCount& wc, real tmin_use, bool any_hit) {
         const uint32_t enc = ~(uint32_t)ref;
         const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
         bool stop = false;
@@ -524,14 +546,14 @@ struct Trav {
         // latency overlaps the current test instead of adding to it (the kernels wait on memory half the time).
         // Measured: bathroom2 +4.4 %, veach-mis +2.3 %, S0 +4.5 %, S4 +5.8 %, cornell unchanged; requesting the
         // next triangle's first 64 bytes instead of 32 costs cornell 7 % (registers) and gains nothing elsewhere.
-        double4 q0n = *reinterpret_cast<const double4*>(tri_at<PAD>(S, first));
+        real4 q0n = *reinterpret_cast<const real4*>(tri_at<PAD>(S, first));
 #endif
         for (uint32_t i = 0; i < cnt; ++i) {
-            double t, al, be;
+            real t, al, be;
             if (COUNT) wc.tris++;
 #if PRT_LEAF_PREFETCH
-            const double4 q0c = q0n;
-            if (i + 1 < cnt) q0n = *reinterpret_cast<const double4*>(tri_at<PAD>(S, first + i + 1));
+            const real4 q0c = q0n;
+            if (i + 1 < cnt) q0n = *reinterpret_cast<const real4*>(tri_at<PAD>(S, first + i + 1));
             if (tri_test(tri_at<PAD>(S, first + i), o, d, tmin_use, hit.t, t, al, be, &q0c, COUNT ? &wc.tris_full : nullptr)) {
 #else
             if (tri_test(tri_at<PAD>(S, first + i), o, d, tmin_use, hit.t, t, al, be, nullptr, COUNT ? &wc.tris_full : nullptr)) {
@@ -551,7 +573,7 @@ struct Trav {
 
     // Leaf round of this lane: the stashed leaf (reached first, usually nearer), then the current one, then pop.
     template <bool COUNT>
-    PRT_DEV void leaf_step(const DScene& S, uint32_t* stk, WorkCount& wc, double tmin_use, bool any_hit) {
+    PRT_DEV void leaf_step(const DScene& S, uint32_t* stk, WorkCount& wc, real tmin_use, bool any_hit) {
         bool stop = false;
         if (pend != 0) {
             stop = test_leaf<COUNT>(S, pend, wc, tmin_use, any_hit);
@@ -580,7 +602,7 @@ struct Trav {
     // `tmin_use` / `any_hit`: the interval's lower end and whether the first accepted triangle ends the traversal.  K1
     // passes its per-ray tmin; K3 derives both from the kind of ray the lane is tracing, so neither is traversal state.
     template <bool COUNT>
-    PRT_DEV void round(const DScene& S, uint32_t* stk, WorkCount& wc, int leaf_batch, int inner_min, double tmin_use,
+    PRT_DEV void round(const DScene& S, uint32_t* stk, WorkCount& wc, int leaf_batch, int inner_min, real tmin_use,
                        bool any_hit) {
         if (COUNT && __ballot(active && cur >= 0) != 0ULL) wc.inner_rounds++;
         if (active && cur >= 0) inner_step<COUNT>(S, stk, wc);
@@ -603,19 +625,19 @@ PRT_DEV int wave_count(bool p) { return __popcll(__ballot(p)); }
 // SRGBToLinear for >= 3 channels — is applied once on the host (same std::pow, same doubles) and the
 // device reads the linearised texel as three doubles: 2 loads per tap instead of 6.
 PRT_DEV d3 tex_pixel(const DScene& S, const DTexture& tx, int x, int y) {
-    const double* p = S.texels_lin + tx.offset + (size_t)(y * tx.width + x) * 3;
+    const real* p = S.texels_lin + tx.offset + (size_t)(y * tx.width + x) * 3;
     return mk3(p[0], p[1], p[2]);
 }
-PRT_DEV d3 tex_value(const DScene& S, int ti, double u, double v) {
+PRT_DEV d3 tex_value(const DScene& S, int ti, real u, real v) {
     const DTexture tx = S.textures[ti];
-    if (!tx.has_data) return mk3(0., 1., 1.);
-    u = fmin(fmax(u, 0.0), 1.0); // std::clamp
-    v = fmin(fmax(v, 0.0), 1.0);
-    double x = u * (tx.width - 1.);
-    double y = (1. - v) * (tx.height - 1.);
+    if (!tx.has_data) return mk3(RL(0.), RL(1.), RL(1.));
+    u = fmin(fmax(u, RL(0.0)), RL(1.0)); // std::clamp
+    v = fmin(fmax(v, RL(0.0)), RL(1.0));
+    real x = u * (tx.width - RL(1.));
+    real y = (RL(1.) - v) * (tx.height - RL(1.));
     int x0 = (int)x, y0 = (int)y;
     int x1 = min(x0 + 1, tx.width - 1), y1 = min(y0 + 1, tx.height - 1);
-    double fx = x - x0, fy = y - y0;
+    real fx = x - x0, fy = y - y0;
     d3 c00 = tex_pixel(S, tx, x0, y0), c10 = tex_pixel(S, tx, x1, y0);
     d3 c01 = tex_pixel(S, tx, x0, y1), c11 = tex_pixel(S, tx, x1, y1);
     d3 c0 = c00 * (1 - fx) + c10 * fx;
@@ -626,31 +648,43 @@ PRT_DEV d3 tex_value(const DScene& S, int ti, double u, double v) {
 // ------------------------------------------------------------------ samplers (RandomNumberGenerator.h:39-73)
 // sin and cos for |x| <= pi/4: the kernel polynomials of fdlibm (k_sin.c / k_cos.c, < 1 ulp), without the range
 // reduction a general sincos() carries.  The concentric map only ever needs this range.
-PRT_DEV void sincos_quarter(double x, double& sn, double& cs) {
-    const double z = x * x;
-    const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
-                      z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-    sn = x + (x * z) * (-1.66666666666666324348e-01 + z * ps);
-    const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
-                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
-    cs = 1.0 - (0.5 * z - z * pc);
+PRT_DEV void sincos_quarter(real x, real& sn, real& cs) {
+    const real z = x * x;
+    if (PRT_F32) { // |x| <= pi/4: Taylor to x^9 / x^8 is below fp32 rounding
+        sn = x + (x * z) * (RL(-1.6666667e-01) + z * (RL(8.3333333e-03) + z * (RL(-1.9841270e-04) + z * RL(2.7557319e-06))));
+        cs = RL(1.0) + z * (RL(-0.5) + z * (RL(4.1666667e-02) + z * (RL(-1.3888889e-03) + z * RL(2.4801587e-05))));
+        return;
+    }
+    const real ps = RL(8.33333333332248946124e-03) + z * (-RL(1.98412698298579493134e-04) + z * (RL(2.75573137070700676789e-06) +
+                      z * (-RL(2.50507602534068634195e-08) + z * RL(1.58969099521155010221e-10))));
+    sn = x + (x * z) * (-RL(1.66666666666666324348e-01) + z * ps);
+    const real pc = z * (RL(4.16666666666666019037e-02) + z * (-RL(1.38888888888741095749e-03) + z * (RL(2.48015872894767294178e-05) +
+                      z * (-RL(2.75573143513906633035e-07) + z * (RL(2.08757232129817482790e-09) + z * -RL(1.13596475577881948265e-11))))));
+    cs = RL(1.0) - (RL(0.5) * z - z * pc);
 }
 // sin and cos of 2*pi*u for u in [0,1): the quarter turn nearest to u is subtracted exactly, the remainder
 // (|r| <= 1/8, i.e. |angle| <= pi/4) goes through the kernel polynomials, the quadrant swaps / negates.
-PRT_DEV void sincos_turns(double u, double& sn, double& cs) {
-    const double k = floor(4.0 * u + 0.5);     // 0..4
-    const double r = u - 0.25 * k;             // exact
-    double s, c;
-    sincos_quarter(2.0 * PRT_PI * r, s, c);
+PRT_DEV void sincos_turns(real u, real& sn, real& cs) {
+    const real k = floor(RL(4.0) * u + RL(0.5));     // 0..4
+    const real r = u - RL(0.25) * k;             // exact
+    real s, c;
+    sincos_quarter(RL(2.0) * PRT_PI * r, s, c);
     const int q = (int)k & 3;
     sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
     cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
 }
+// sin / cos of theta = 2 pi u: the library call the reference makes in fp64; in fp32 the hardware instructions, which
+// take their argument in turns (v_sin_f32 / v_cos_f32)
+PRT_DEV void sincos_any(double theta, double, double& sn, double& cs) { sincos(theta, &sn, &cs); }
+PRT_DEV void sincos_any(float, float u, float& sn, float& cs) {
+    sn = __builtin_amdgcn_sinf(u);
+    cs = __builtin_amdgcn_cosf(u);
+}
 PRT_DEV d2 disk_concentric(d2 u) {
-    d2 off = {2. * u.x - 1., 2. * u.y - 1.};
-    if (off.x == 0. && off.y == 0.) return {0., 0.};
+    d2 off = {RL(2.) * u.x - RL(1.), RL(2.) * u.y - RL(1.)};
+    if (off.x == RL(0.) && off.y == RL(0.)) return {RL(0.), RL(0.)};
     // RandomNumberGenerator.h:39-56: theta = pi/4 * (y/x), or pi/2 - pi/4 * (x/y) — i.e. sin and cos swapped
-    double sn, cs;
+    real sn, cs;
     if (fabs(off.x) > fabs(off.y)) {
         sincos_quarter(PRT_PI_OVER_4 * fast_div(off.y, off.x), sn, cs);
         return {off.x * cs, off.x * sn};
@@ -661,10 +695,10 @@ PRT_DEV d2 disk_concentric(d2 u) {
 // SampleCosineHemisphere: glm::dvec2(RandomDouble(), RandomDouble()) as compiled by g++ (right-to-left):
 // u.y = first draw, u.x = second draw.
 PRT_DEV d3 cosine_hemisphere(Rng& rng) {
-    double first = rng.next();
-    double second = rng.next();
+    real first = rng.next();
+    real second = rng.next();
     d2 dd = disk_concentric(d2{second, first});
-    double z = fast_sqrt(fmax(0.0, 1. - dd.x * dd.x - dd.y * dd.y));
+    real z = fast_sqrt(fmax(RL(0.0), RL(1.) - dd.x * dd.x - dd.y * dd.y));
     return mk3(dd.x, dd.y, z);
 }
 
@@ -681,33 +715,33 @@ PRT_DEV d3 local_to_world(d3 l, const Frame& f) {
     return normalize(l.x * f.t + l.y * bit + l.z * f.n);
 }
 PRT_DEV d3 reflect_z(d3 wo) { // Reflect(wo, (0,0,1)) = -wo + 2*dot(wo,n)*n
-    double dn = wo.x * 0. + wo.y * 0. + wo.z * 1.;
-    d3 n2 = (2. * dn) * mk3(0., 0., 1.);
+    real dn = wo.x * RL(0.) + wo.y * RL(0.) + wo.z * RL(1.);
+    d3 n2 = (RL(2.) * dn) * mk3(RL(0.), RL(0.), RL(1.));
     return -wo + n2;
 }
-PRT_DEV d3 reflect(d3 wo, d3 n) { return -wo + 2. * dot(wo, n) * n; }
+PRT_DEV d3 reflect(d3 wo, d3 n) { return -wo + RL(2.) * dot(wo, n) * n; }
 
 // ------------------------------------------------------------------ CookTorrance (Material.h:368-521, MaterialUtils.h)
 struct Cx {
-    double re, im;
+    real re, im;
 };
-PRT_DEV Cx cx(double r, double i = 0.0) { return {r, i}; }
+PRT_DEV Cx cx(real r, real i = RL(0.0)) { return {r, i}; }
 PRT_DEV Cx operator+(Cx a, Cx b) { return {a.re + b.re, a.im + b.im}; }
 PRT_DEV Cx operator-(Cx a, Cx b) { return {a.re - b.re, a.im - b.im}; }
 PRT_DEV Cx operator*(Cx a, Cx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 PRT_DEV Cx operator/(Cx a, Cx z) {
-    double scale = 1 / (z.re * z.re + z.im * z.im);
+    real scale = 1 / (z.re * z.re + z.im * z.im);
     return {scale * (a.re * z.re + a.im * z.im), scale * (a.im * z.re - a.re * z.im)};
 }
-PRT_DEV double cnorm(Cx z) { return z.re * z.re + z.im * z.im; }
+PRT_DEV real cnorm(Cx z) { return z.re * z.re + z.im * z.im; }
 PRT_DEV Cx csqrt_(Cx z) { // MaterialUtils.h:54-65
-    double n = sqrt(cnorm(z)), t1 = sqrt(.5 * (n + fabs(z.re))), t2 = .5 * z.im / t1;
+    real n = ieee_sqrt(cnorm(z)), t1 = ieee_sqrt(RL(.5) * (n + fabs(z.re))), t2 = RL(.5) * z.im / t1;
     if (n == 0) return cx(0);
     if (z.re >= 0) return {t1, t2};
     return {fabs(t2), copysign(t1, z.im)};
 }
-PRT_DEV double clampd(double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); }
-PRT_DEV double sqr(double v) { return v * v; }
+PRT_DEV real clampd(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
+PRT_DEV real sqr(real v) { return v * v; }
 // x^y for the Phong lobe (Material.h:205,223,247,260) as exp(y*log(x)): |y*log x| <= ~50 here, so the
 // result is within ~1e-14 relative of pow() — far inside the 1e-9 parity tolerance — at a third of the
 // instructions and registers of the fp64 library pow.  x = 0 -> 0, x < 0 -> NaN (every caller then
@@ -715,6 +749,9 @@ PRT_DEV double sqr(double v) { return v * v; }
 #ifndef PRT_SLIM_POW
 #define PRT_SLIM_POW 1
 #endif
+PRT_DEV float pow_pos(float x, float y) { // fp32 fast mode: v_exp_f32(y * v_log_f32(x)) (base 2); x = 0 -> exp2(-inf) = 0
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+}
 #if PRT_SLIM_POW
 // Written out (fdlibm's log and a degree-13 exp on the reduced argument, both < 2 ulp) instead of calling the library
 // exp and log: a third of their instructions and, above all, ~25 fewer live registers at the Phong lobe — the
@@ -724,100 +761,100 @@ PRT_DEV double pow_pos(double x, double y) {
     // log(x): x = m * 2^k with m in [sqrt(1/2), sqrt(2)), f = m - 1, s = f / (2 + f), log(1 + f) = f - (f^2/2 - s (f^2/2 + R(s^2)))
     double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
     int k = __builtin_amdgcn_frexp_exp(x);
-    const bool lo = m < 0.70710678118654752440;
-    m = lo ? 2.0 * m : m;
+    const bool lo = m < (0.70710678118654752440);
+    m = lo ? (2.0) * m : m;
     k = lo ? k - 1 : k;
-    const double f = m - 1.0;
-    const double s = fast_div(f, 2.0 + f);
+    const double f = m - (1.0);
+    const double s = fast_div(f, (2.0) + f);
     const double z = s * s, w = z * z;
-    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
-    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
-    const double hfsq = 0.5 * f * f;
+    const double t1 = w * fma(w, fma(w, (1.531383769920937332e-01), (2.222219843214978396e-01)), (3.999999999940941908e-01));
+    const double t2 = z * fma(w, fma(w, fma(w, (1.479819860511658591e-01), (1.818357216161805012e-01)), (2.857142874366239149e-01)), (6.666666666666735130e-01));
+    const double hfsq = (0.5) * f * f;
     const double dk = (double)k;
-    const double lg = dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + (t1 + t2), dk * 1.90821492927058770002e-10)) - f);
+    const double lg = dk * (6.93147180369123816490e-01) - ((hfsq - fma(s, hfsq + (t1 + t2), dk * (1.90821492927058770002e-10))) - f);
     // exp(t): t = n ln2 + r, |r| <= ln2 / 2
-    const double t = fmax(y * lg, -1000.0);
-    const double n = rint(t * 1.44269504088896338700e+00);
-    double r = fma(n, -6.93147180369123816490e-01, t);
-    r = fma(n, -1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;                    // 1/13!
-    p = fma(p, r, 2.08767569878681e-09);                   // 1/12!
-    p = fma(p, r, 2.505210838544172e-08);
-    p = fma(p, r, 2.755731922398589e-07);
-    p = fma(p, r, 2.7557319223985893e-06);
-    p = fma(p, r, 2.48015873015873e-05);
-    p = fma(p, r, 1.984126984126984e-04);
-    p = fma(p, r, 1.388888888888889e-03);
-    p = fma(p, r, 8.333333333333333e-03);
-    p = fma(p, r, 4.1666666666666664e-02);
-    p = fma(p, r, 1.6666666666666666e-01);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
+    const double t = fmax(y * lg, -(1000.0));
+    const double n = rint(t * (1.44269504088896338700e+00));
+    double r = fma(n, -(6.93147180369123816490e-01), t);
+    r = fma(n, -(1.90821492927058770002e-10), r);
+    double p = (1.6059043836821613e-10);                    // 1/13!
+    p = fma(p, r, (2.08767569878681e-09));                   // 1/12!
+    p = fma(p, r, (2.505210838544172e-08));
+    p = fma(p, r, (2.755731922398589e-07));
+    p = fma(p, r, (2.7557319223985893e-06));
+    p = fma(p, r, (2.48015873015873e-05));
+    p = fma(p, r, (1.984126984126984e-04));
+    p = fma(p, r, (1.388888888888889e-03));
+    p = fma(p, r, (8.333333333333333e-03));
+    p = fma(p, r, (4.1666666666666664e-02));
+    p = fma(p, r, (1.6666666666666666e-01));
+    p = fma(p, r, (0.5));
+    p = fma(p, r, (1.0));
+    p = fma(p, r, (1.0));
     const double e = __builtin_amdgcn_ldexp(p, (int)n);
-    return x > 0.0 ? e : 0.0;
+    return x > (0.0) ? e : (0.0);
 }
 #else
 PRT_DEV double pow_pos(double x, double y) { return exp(y * log(x)); }
 #endif
-PRT_DEV double fr_complex(double cosTheta_i, Cx eta) { // MaterialUtils.h:100-111
+PRT_DEV real fr_complex(real cosTheta_i, Cx eta) { // MaterialUtils.h:100-111
     cosTheta_i = clampd(cosTheta_i, 0, 1);
-    double sin2Theta_i = 1 - sqr(cosTheta_i);
+    real sin2Theta_i = 1 - sqr(cosTheta_i);
     Cx sin2Theta_t = cx(sin2Theta_i) / (eta * eta);
     Cx cosTheta_t = csqrt_(cx(1) - sin2Theta_t);
     Cx r_parl = (eta * cx(cosTheta_i) - cosTheta_t) / (eta * cx(cosTheta_i) + cosTheta_t);
     Cx r_perp = (cx(cosTheta_i) - eta * cosTheta_t) / (cx(cosTheta_i) + eta * cosTheta_t);
     return (cnorm(r_parl) + cnorm(r_perp)) / 2;
 }
-PRT_DEV double cos2theta(d3 w) { return sqr(w.z); }
-PRT_DEV double sin2theta(d3 w) { return fmax(0., 1 - cos2theta(w)); }
-PRT_DEV double tan2theta(d3 w) { return sin2theta(w) / cos2theta(w); }
-PRT_DEV double cosphi(d3 w) {
-    double st = sqrt(sin2theta(w));
+PRT_DEV real cos2theta(d3 w) { return sqr(w.z); }
+PRT_DEV real sin2theta(d3 w) { return fmax(RL(0.), 1 - cos2theta(w)); }
+PRT_DEV real tan2theta(d3 w) { return sin2theta(w) / cos2theta(w); }
+PRT_DEV real cosphi(d3 w) {
+    real st = ieee_sqrt(sin2theta(w));
     return (st == 0) ? 1 : clampd(w.x / st, -1, 1);
 }
-PRT_DEV double sinphi(d3 w) {
-    double st = sqrt(sin2theta(w));
+PRT_DEV real sinphi(d3 w) {
+    real st = ieee_sqrt(sin2theta(w));
     return (st == 0) ? 0 : clampd(w.y / st, -1, 1);
 }
-PRT_DEV double ct_D(const DMaterial& m, d3 wm) {
-    double t2 = tan2theta(wm);
+PRT_DEV real ct_D(const DMaterial& m, d3 wm) {
+    real t2 = tan2theta(wm);
     if (isinf(t2)) return 0;
-    double cos4 = sqr(cos2theta(wm));
-    double e = t2 * (sqr(cosphi(wm) / m.alpha_x) + sqr(sinphi(wm) / m.alpha_y));
+    real cos4 = sqr(cos2theta(wm));
+    real e = t2 * (sqr(cosphi(wm) / m.alpha_x) + sqr(sinphi(wm) / m.alpha_y));
     return 1 / (PRT_PI * m.alpha_x * m.alpha_y * cos4 * sqr(1 + e));
 }
-PRT_DEV double ct_lambda(const DMaterial& m, d3 w) {
-    double t2 = tan2theta(w);
+PRT_DEV real ct_lambda(const DMaterial& m, d3 w) {
+    real t2 = tan2theta(w);
     if (isinf(t2)) return 0;
-    double alpha2 = sqr(cosphi(w) * m.alpha_x) + sqr(sinphi(w) * m.alpha_y);
-    return (sqrt(1 + alpha2 * t2) - 1) / 2;
+    real alpha2 = sqr(cosphi(w) * m.alpha_x) + sqr(sinphi(w) * m.alpha_y);
+    return (ieee_sqrt(1 + alpha2 * t2) - 1) / 2;
 }
-PRT_DEV double ct_G1(const DMaterial& m, d3 w) { return 1 / (1 + ct_lambda(m, w)); }
-PRT_DEV double ct_G(const DMaterial& m, d3 wo, d3 wi) { return 1 / (1 + ct_lambda(m, wo) + ct_lambda(m, wi)); }
-PRT_DEV double ct_Dv(const DMaterial& m, d3 w, d3 wm) {
+PRT_DEV real ct_G1(const DMaterial& m, d3 w) { return 1 / (1 + ct_lambda(m, w)); }
+PRT_DEV real ct_G(const DMaterial& m, d3 wo, d3 wi) { return 1 / (1 + ct_lambda(m, wo) + ct_lambda(m, wi)); }
+PRT_DEV real ct_Dv(const DMaterial& m, d3 w, d3 wm) {
     return ct_G1(m, w) / fabs(w.z) * ct_D(m, wm) * fabs(dot(w, wm));
 }
 PRT_DEV d3 ct_fresnel(const DMaterial& m, d3 wo, d3 wm) {
-    double c = fabs(dot(wo, wm));
+    real c = fabs(dot(wo, wm));
     return mk3(fr_complex(c, cx(m.eta[0], m.k[0])), fr_complex(c, cx(m.eta[1], m.k[1])),
                fr_complex(c, cx(m.eta[2], m.k[2])));
 }
 PRT_DEV d3 ct_sample_wm(const DMaterial& m, d3 w, d2 u) { // Material.h:412-435
     d3 wh = normalize(mk3(m.alpha_x * w.x, m.alpha_y * w.y, w.z));
     if (wh.z < 0) wh = -wh;
-    d3 T1 = (wh.z < 0.99999) ? normalize(cross(mk3(0., 0., 1.), wh)) : mk3(1, 0, 0);
+    d3 T1 = (wh.z < RL(0.99999)) ? normalize(cross(mk3(RL(0.), RL(0.), RL(1.)), wh)) : mk3(1, 0, 0);
     d3 T2 = cross(wh, T1);
-    double r = sqrt(u.x), theta = 2 * PRT_PI * u.y; // SampleUniformDiskPolar
-    double sn, cs;
-    sincos(theta, &sn, &cs);
+    real r = ieee_sqrt(u.x), theta = 2 * PRT_PI * u.y; // SampleUniformDiskPolar
+    real sn, cs;
+    sincos_any(theta, u.y, sn, cs);
     d2 p = {r * cs, r * sn};
-    double h = sqrt(1 - sqr(p.x));
-    double lx = (1 + wh.z) / 2;
+    real h = ieee_sqrt(1 - sqr(p.x));
+    real lx = (1 + wh.z) / 2;
     p.y = (1 - lx) * h + lx * p.y; // Lerp
-    double pz = sqrt(fmax(0., 1. - (sqr(p.x) + sqr(p.y))));
+    real pz = ieee_sqrt(fmax(RL(0.), RL(1.) - (sqr(p.x) + sqr(p.y))));
     d3 nh = p.x * T1 + p.y * T2 + pz * wh;
-    return normalize(mk3(m.alpha_x * nh.x, m.alpha_y * nh.y, fmax(1e-6, nh.z)));
+    return normalize(mk3(m.alpha_x * nh.x, m.alpha_y * nh.y, fmax(RL(1e-6), nh.z)));
 }
 
 // ------------------------------------------------------------------ Material::Eval for NEE
@@ -844,22 +881,22 @@ template <int FEAT>
 PRT_DEV d3 mat_eval(const DScene& S, const DMaterial& m, d3 wi, d3 wo, d2 uv, Rng& rng) {
     if (m.type == 0) return mat_kd<FEAT>(S, m, uv) * PRT_INV_PI;
     if ((FEAT & PRT_FEAT_PHONG) && m.type == 1) {
-        double u = rng.next();
+        real u = rng.next();
         if (u < m.pkd) {
             if (wi.z <= 0) return mk3(0, 0, 0);
             return mat_kd<FEAT>(S, m, uv) * PRT_INV_PI;
         } else if (m.pkd <= u && u < m.pkd + m.pks) {
             if (wi.z <= 0) return mk3(0, 0, 0);
             d3 lr = normalize(reflect_z(wo));
-            double ca = fmax(0., dot(wi, lr));
-            if (ca <= 0.) return mk3(0, 0, 0);
-            return mat_ks<FEAT>(S, m, uv) * (m.ns + 2.) * PRT_INV_2PI * pow_pos(ca, m.ns);
+            real ca = fmax(RL(0.), dot(wi, lr));
+            if (ca <= RL(0.)) return mk3(0, 0, 0);
+            return mat_ks<FEAT>(S, m, uv) * (m.ns + RL(2.)) * PRT_INV_2PI * pow_pos(ca, m.ns);
         }
         return mk3(0, 0, 0);
     }
     if ((FEAT & PRT_FEAT_CT) && m.type == 3) {
         if (!(wo.z * wi.z > 0)) return mk3(0, 0, 0);
-        double co = fabs(wo.z), ci = fabs(wi.z);
+        real co = fabs(wo.z), ci = fabs(wi.z);
         if (ci == 0 || co == 0) return mk3(0, 0, 0);
         d3 wm = wi + wo;
         if (sqr(wm.x) + sqr(wm.y) + sqr(wm.z) == 0) return mk3(0, 0, 0);
@@ -875,14 +912,14 @@ PRT_DEV d3 mat_eval(const DScene& S, const DMaterial& m, d3 wi, d3 wo, d2 uv, Rn
 // direction, `att` = f * cos / pdf.  rd = incoming ray direction (unnormalised for camera rays).
 template <int FEAT>
 PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame& f, d2 uv, Rng& rng, d3& att,
-                         d3& wi_world, bool have_fr = false, d3 fr_pre = d3{0., 0., 0.}) {
+                         d3& wi_world, bool have_fr = false, d3 fr_pre = d3{RL(0.), RL(0.), RL(0.)}) {
     if (!(FEAT & PRT_FEAT_PHONG) && m.type == 1) return false; // not reachable: the host picks a permutation that
     if (!(FEAT & PRT_FEAT_CT) && m.type == 3) return false;    // covers every material type of the scene
     switch (m.type) {
     case 0: { // Lambertian, Material.h:106-151
         d3 wi = cosine_hemisphere(rng);
-        while (wi.z <= 0.) wi = cosine_hemisphere(rng);
-        double pdf = wi.z * PRT_INV_PI;
+        while (wi.z <= RL(0.)) wi = cosine_hemisphere(rng);
+        real pdf = wi.z * PRT_INV_PI;
         // textured surfaces: the light evaluation of this vertex (same pass) has already looked the albedo up
         d3 fr = ((FEAT & PRT_FEAT_TEX) && have_fr) ? fr_pre : mat_kd<FEAT>(S, m, uv) * PRT_INV_PI;
         wi_world = local_to_world(wi, f);
@@ -892,27 +929,27 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
     case 1: { // PhoneReflectance, Material.h:183-285
         d3 wo = world_to_local(-rd, f);
         d3 wi = mk3(0, 0, 0), fr = mk3(0, 0, 0);
-        double pdf = 0;
+        real pdf = 0;
         bool spec = false, spec_ok = false;
-        double u = rng.next();
+        real u = rng.next();
         if (u < m.pkd) {
             wi = cosine_hemisphere(rng);
-            while (wi.z <= 0.) wi = cosine_hemisphere(rng);
+            while (wi.z <= RL(0.)) wi = cosine_hemisphere(rng);
             pdf = wi.z * PRT_INV_PI;
             fr = mat_kd<FEAT>(S, m, uv) * PRT_INV_PI;
         } else if (m.pkd <= u && u < m.pkd + m.pks) {
-            double u1 = rng.next(), u2 = rng.next();
+            real u1 = rng.next(), u2 = rng.next();
             // alpha = acos(u1^(1/(Ns+1))), phi = 2 pi u2 (Material.h:205-208): cos(alpha) IS the power, sin(alpha)
             // its Pythagorean complement, and sin/cos(2 pi u2) reduce exactly in u2 to a quarter-period polynomial —
             // no acos, no general-range sincos (their results differ from these by rounding only)
-            double sa, ca, sp, cp;
-            ca = fmin(pow_pos(u1, m.inv_ns1), 1.0);
-            sa = sqrt(fmax(0.0, 1.0 - ca * ca));
+            real sa, ca, sp, cp;
+            ca = fmin(pow_pos(u1, m.inv_ns1), RL(1.0));
+            sa = ieee_sqrt(fmax(RL(0.0), RL(1.0) - ca * ca));
             sincos_turns(u2, sp, cp);
             d3 rw = mk3(sa * cp, sa * sp, ca);
             // ReflectiveSpaceToLocal, Material.h:299-311
             d3 lr = normalize(reflect_z(wo));
-            d3 V = (fabs(lr.x) > 0.9 ? mk3(0., 1., 0.) : mk3(1., 0., 0.));
+            d3 V = (fabs(lr.x) > RL(0.9) ? mk3(RL(0.), RL(1.), RL(0.)) : mk3(RL(1.), RL(0.), RL(0.)));
             d3 T = normalize(cross(V, lr));
             d3 B = cross(lr, T);
             wi = rw.x * T + rw.y * B + rw.z * lr;
@@ -920,38 +957,38 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
             // direction, and cos(alpha) = dot(wi, lr) IS ca = u1^(1/(Ns+1)) (T, B, lr are orthonormal), so the power is
             // u1^(Ns/(Ns+1)): positive whenever u1 is (u1 >= 2^-31 or 0 — it cannot underflow), and it cancels in
             // f cos / pdf = Ks (Ns+2)/(Ns+1) cos(theta_i).  No second pow (one log + one exp less per specular sample).
-            spec_ok = wi.z > 0. && u1 > 0.;
+            spec_ok = wi.z > RL(0.) && u1 > RL(0.);
             spec = true;
             fr = mat_ks<FEAT>(S, m, uv) * m.spec_scale;
         }
         wi_world = local_to_world(wi, f);
         if (spec) att = spec_ok ? fr * wi.z : mk3(0, 0, 0); // below the horizon: pdf = 0, attenuation unassigned upstream, 0 here (B13)
-        else if (pdf > 0. && wi.z > 0) att = fr * wi.z / pdf;
+        else if (pdf > RL(0.) && wi.z > 0) att = fr * wi.z / pdf;
         else att = mk3(0, 0, 0); // reference leaves it unassigned (Material.h:280-282); defined 0 (B13)
         return true;
     }
     case 2: { // PerfectMirror, Material.h:334-363
         d3 wo = world_to_local(-rd, f);
         d3 wi = reflect_z(wo);
-        double c = wi.z;
-        d3 fr = mk3(1.0 / c, 1.0 / c, 1.0 / c);
+        real c = wi.z;
+        d3 fr = mk3(RL(1.0) / c, RL(1.0) / c, RL(1.0) / c);
         wi_world = local_to_world(wi, f);
-        att = fr * c / 1.0;
+        att = fr * c / RL(1.0);
         return true;
     }
     case 3: { // CookTorrance, Material.h:437-516
         d3 wo = normalize(world_to_local(-rd, f));
         if (wo.z == 0) return false;
-        double first = rng.next();
-        double second = rng.next();
+        real first = rng.next();
+        real second = rng.next();
         d3 wm = ct_sample_wm(m, wo, d2{second, first});
         d3 wi = reflect(wo, wm);
         if (!(wo.z * wi.z > 0)) return false;
-        double pdf = ct_Dv(m, wo, wm) / (4. * fabs(dot(wo, wm)));
-        double co = fabs(wo.z), ci = fabs(wi.z);
+        real pdf = ct_Dv(m, wo, wm) / (RL(4.) * fabs(dot(wo, wm)));
+        real co = fabs(wo.z), ci = fabs(wi.z);
         if (ci == 0 || co == 0) return false;
         d3 F = ct_fresnel(m, wo, wm);
-        d3 fr = ct_D(m, wm) * F * ct_G(m, wo, wi) / (4. * ci * co);
+        d3 fr = ct_D(m, wm) * F * ct_G(m, wo, wi) / (RL(4.) * ci * co);
         att = fr * wi.z / pdf;
         wi_world = local_to_world(wi, f);
         return true;
@@ -962,11 +999,11 @@ PRT_DEV bool mat_scatter(const DScene& S, const DMaterial& m, d3 rd, const Frame
 
 // ------------------------------------------------------------------ lights.Sample
 // HittableList::Sample (HittableList.h:44-59, one discarded draw) -> BVHNode::Sample (BVH.cpp:62-67,
-// p = sqrt(xi)*A truncated to float) -> TraverseSample (BVH.cpp:86-100) -> Triangle::Sample
+// p = ieee_sqrt(xi)*A truncated to float) -> TraverseSample (BVH.cpp:86-100) -> Triangle::Sample
 // (Triangle.cpp:84-93).  pdf = (1/area)*area/totalArea evaluated in that order.
 struct LightPick {
     d3 pos, n;
-    double pdf;
+    real pdf;
     int32_t tri; // index into light_tris
     bool front;
 };
@@ -977,23 +1014,23 @@ template <bool LLDS>
 PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLightNode* lds_nodes = nullptr, int32_t n_lds = 0,
                                 const DLightTri* lds_tris = nullptr, int32_t n_tris_lds = 0) {
     (void)rng.next();
-    double p = sqrt(rng.next()) * S.light_area; // IEEE: p is truncated to float and compared against the CDF — the pick stays bit-exact
+    real p = ieee_sqrt(rng.next()) * S.light_area; // IEEE: p is truncated to float and compared against the CDF — the pick stays bit-exact
     float pf = (float)p;
     int32_t node = S.light_root;
     while (node >= 0) {
         DLightNode ln;
         if (LLDS && node < n_lds) ln = lds_nodes[node];
         else ln = S.light_nodes[node];
-        if ((double)pf < ln.left_area) node = ln.left;
+        if ((real)pf < ln.left_area) node = ln.left;
         else {
-            pf = (float)((double)pf - ln.left_area);
+            pf = (float)((real)pf - ln.left_area);
             node = ln.right;
         }
     }
     LightPick lp;
     lp.tri = ~node;
-    double x = fast_sqrt(rng.next());
-    double y = rng.next();
+    real x = fast_sqrt(rng.next());
+    real y = rng.next();
     d3 v0, v1, v2, n;
     if (LLDS && n_tris_lds > 0) { // uniform: a scene's light triangles are staged all or not at all
         const DLightTri* lt = lds_tris + lp.tri;
@@ -1004,9 +1041,9 @@ PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLig
         v0 = ld3(lt->v0); v1 = ld3(lt->v1); v2 = ld3(lt->v2); n = ld3(lt->n);
         lp.pdf = lt->pdf; // (1/area)*area/total_area, evaluated in that order on the host
     }
-    lp.pos = v0 * (1.0 - x) + v1 * (x * (1.0 - y)) + v2 * (x * y);
+    lp.pos = v0 * (RL(1.0) - x) + v1 * (x * (RL(1.0) - y)) + v2 * (x * y);
     d3 dir = lp.pos - origin;
-    lp.front = dot(dir, n) < 0.;
+    lp.front = dot(dir, n) < RL(0.);
     lp.n = lp.front ? n : -n;
     return lp;
 }

@@ -23,6 +23,9 @@ struct HostTri {
 
 struct BuiltBVH {
     std::vector<DNode> nodes;    // nodes[0] is the root
+    std::vector<DNode> nodes_shallow; // 4-wide trees that can need more than PRT_STACK_SHALLOW stack entries: the same
+                                      // binary tree collapsed with that budget (same leaves, same triangle order); else empty
+    int stack_need = 0;          // stack entries a traversal of `nodes` can need at most
     std::vector<uint32_t> order; // BVH leaf order -> index into the HostTri array
     uint32_t depth = 0;
     float coord_scale = 1.0f;    // >= |every box coordinate|
@@ -65,6 +68,8 @@ void setup_materials(const PrtSceneDesc& d, std::vector<DMaterial>& out);
 bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err);
 // Structural check of a flattened tree (refs in range, every triangle in exactly one leaf, stack bound).
 bool validate_nodes(const DNode* nodes, size_t n_nodes, size_t n_tris, std::string* err);
+// Largest number of stack entries a traversal of this tree can need (<= PRT_STACK_DEPTH for a builder's tree).
+int tree_stack_need(const DNode* nodes, size_t n_nodes);
 // Same tree family built on the current HIP device from the same fp32 boxes (n >= 2): Morton sort, box
 // segment tree, level-synchronous SAH splits along the Morton order.  Returns false with *err set.
 bool build_bvh_device(const PrimBox* h_boxes, size_t n, DeviceBVH& out, std::string* err);

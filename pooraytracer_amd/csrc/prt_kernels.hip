@@ -26,6 +26,19 @@
 #include "../../include/prt.h"
 #include "prt_device.h"
 
+// This file is compiled twice: as it stands (fp64, the reference's arithmetic: namespace prt, every kernel) and through
+// prt_kernels_f32.hip with PRT_REAL = float (the fp32 fast mode: namespace prt32, K1 and K3 only — K5, the tone map and
+// the test hooks work on fp64 buffers in either mode and exist once).
+#ifndef PRT_F32_TU
+#define PRT_F32_TU 0
+#endif
+#if PRT_F32_TU
+#define PRT_NS prt32
+#else
+#define PRT_NS prt
+#endif
+#define PRT_DYN_STACK PRT_F32_TU // K3's traversal stacks in dynamic LDS, sized per launch (DRenderParams::stack_depth)
+
 // minimum resident waves per SIMD the register allocator must leave room for in K3
 #ifndef PRT_RENDER_WAVES
 #define PRT_RENDER_WAVES 2
@@ -39,7 +52,14 @@
 #ifndef PRT_RENDER_WAVES_PHONG
 #define PRT_RENDER_WAVES_PHONG 2 // PhoneReflectance without textures (veach-mis-class scenes)
 #endif
+#ifndef PRT_F32_PK_LEAN
+#define PRT_F32_PK_LEAN 0 // measured: no difference on the lean fp32 kernel
+#endif
+#ifndef PRT_F32_WAVES
+#define PRT_F32_WAVES 3 // fp32 fast mode: resident waves per SIMD of every K3 permutation
+#endif
 constexpr int render_waves(int feat) {
+    if (PRT_F32_TU) return PRT_F32_WAVES;
     return feat == 0 ? PRT_RENDER_WAVES_LEAN
          : feat == PRT_FEAT_TEX ? PRT_RENDER_WAVES_TEX
          : feat == PRT_FEAT_PHONG ? PRT_RENDER_WAVES_PHONG
@@ -100,8 +120,8 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
     WorkCount wc{0, 0, 0, 0, 0};
     uint32_t nrays = 0;
     Trav<PAD> tr;
-    tr.init(S, mk3(0, 0, 0), mk3(0, 0, 1), 0.0, 0.0);
-    tr.hit.alpha = tr.hit.beta = 0.0;
+    tr.init(S, mk3(0, 0, 0), mk3(0, 0, 1), RL(0.0), RL(0.0));
+    tr.hit.alpha = tr.hit.beta = RL(0.0);
     tr.active = false;
     bool have = false;
     size_t my = 0;
@@ -120,7 +140,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
                     out.alpha = tr.hit.alpha;
                     out.beta = tr.hit.beta;
                     out.prim = S.shade[tr.hit.tri].prim;
-                    out.front = dot(tr.d, nrm) < 0. ? 1 : 0; // HitRecord::SetFaceNormal, Hittable.cpp:8-13
+                    out.front = dot(tr.d, nrm) < RL(0.) ? 1 : 0; // HitRecord::SetFaceNormal, Hittable.cpp:8-13
                 } else {
                     out.t = PRT_INF;
                     out.alpha = out.beta = 0;
@@ -148,7 +168,7 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
                     if (idx < pool_end) {
                         const double4* rp = reinterpret_cast<const double4*>(rays + idx);
                         const double4 r0 = rp[0], r1 = rp[1];
-                        tr.init(S, mk3(r0.x, r0.y, r0.z), mk3(r1.x, r1.y, r1.z), r0.w, r1.w);
+                        tr.init(S, mk3((real)r0.x, (real)r0.y, (real)r0.z), mk3((real)r1.x, (real)r1.y, (real)r1.z), (real)r0.w, (real)r1.w); // PrtRay is fp64 at the ABI in either mode
                         my = (size_t)idx;
                         have = true;
                         nrays++;
@@ -191,20 +211,20 @@ struct ShadeCtx {
 };
 // `rd` = the direction the hit was reached along, (alpha, beta, tri) = the hit (read in place: no HitInfo copy)
 template <int FEAT, bool PAD>
-PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 rd, double alpha, double beta, int32_t tri) {
+PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 rd, real alpha, real beta, int32_t tri) {
     ShadeCtx c;
     const DTriShade* sh = S.shade + tri;
     const DTri* T = tri_at<PAD>(S, (uint32_t)tri);
     const d3 gn = mk3(T->n[0], T->n[1], T->n[2]);
-    const bool front = dot(rd, gn) < 0.;
+    const bool front = dot(rd, gn) < RL(0.);
     c.f.n = front ? gn : -gn;
     c.f.t = ld3(sh->tangent);
     if (FEAT & PRT_FEAT_TEX) { // texture coordinates are only read by image-textured materials
-        const double w0 = 1. - alpha - beta;
+        const real w0 = RL(1.) - alpha - beta;
         c.uv.x = w0 * sh->uv0[0] + alpha * sh->uv1[0] + beta * sh->uv2[0];
         c.uv.y = w0 * sh->uv0[1] + alpha * sh->uv1[1] + beta * sh->uv2[1];
     } else {
-        c.uv.x = c.uv.y = 0.0;
+        c.uv.x = c.uv.y = RL(0.0);
     }
     c.material = sh->material;
     return c;
@@ -213,15 +233,26 @@ PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 rd, double alpha, double beta, int
 template <bool COUNT, int FEAT, bool LLDS, bool PAD>
 __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     DScene S, DCamera C, DRenderParams P, double* __restrict__ partial, DCounters* ctr) {
-    __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
     __shared__ uint32_t s_qoff[PRT_BLOCK / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Dynamic LDS, sized by the host: the four waves' traversal stacks (P.stack_depth entries per lane, lane-strided),
+    // then the shading tables.  The depth is a launch parameter because it decides how many blocks a CU holds: a tree
+    // that needs at most 32 entries leaves room for a fourth block (the fp32 kernels have the registers for it).
+    // (The fp64 kernels sit at their register limit with three blocks per CU whatever the stacks take, so theirs stay
+    // a static array of PRT_STACK_DEPTH entries: a run-time depth cost them 6 more spilled scalar registers and 1 %.)
+    extern __shared__ __align__(16) unsigned char s_dyn_all[];
+#if PRT_DYN_STACK
+    uint32_t* stk = reinterpret_cast<uint32_t*>(s_dyn_all) + (size_t)(wave * P.stack_depth) * 64 + lane;
+    unsigned char* s_dyn = s_dyn_all + (size_t)(PRT_BLOCK / 64) * P.stack_depth * 64 * sizeof(uint32_t);
+#else
+    __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
     uint32_t* stk = &s_stack[wave][0][lane];
+    unsigned char* s_dyn = s_dyn_all;
+#endif
     if (lane == 0) {
         s_qoff[wave] = 0;
     }
-    // light tree in LDS (dynamic allocation sized by the host; see sample_lights)
-    extern __shared__ __align__(16) unsigned char s_dyn[];
+    // light tree in LDS (see sample_lights)
     const DLightNode* lds_lights = reinterpret_cast<const DLightNode*>(s_dyn);
     // ... followed by the whole material table (the host only selects LLDS when it fits): its fields are read
     // several times per path vertex, and every one of those reads is otherwise a texture-addresser instruction
@@ -272,14 +303,14 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     // the light pick need to be kept.
     d3 rd = mk3(0, 0, 1);        // incoming direction at the shading point (valid in ST_SHADOW)
     int32_t sh_tri = -1;
-    double ldist = 0;            // distance to the sampled light point (valid in ST_SHADOW)
+    real ldist = 0;              // distance to the sampled light point (valid in ST_SHADOW)
     int32_t ltri = 0;
     Rng rng;
     rng.s = 0;
-    const double inv_spp = 1.0 / P.spp; // pixelSamplesScale, Camera.cpp:83
-    Trav<PAD, PRT_BOX_PK && FEAT != 0> tr;
-    tr.init(S, mk3(0, 0, 0), rd, 0.0, 0.0);
-    tr.hit.alpha = tr.hit.beta = 0.0; // init() leaves the barycentrics alone (they survive shadow traversals)
+    const real inv_spp = RL(1.0) / (real)P.spp; // pixelSamplesScale, Camera.cpp:83
+    Trav<PAD, PRT_BOX_PK && (FEAT != 0 || PRT_F32_PK_LEAN)> tr; // fp32: registers to spare in every permutation
+    tr.init(S, mk3(0, 0, 0), rd, RL(0.0), RL(0.0));
+    tr.hit.alpha = tr.hit.beta = RL(0.0); // init() leaves the barycentrics alone (they survive shadow traversals)
     tr.active = false;
 
 #if PRT_K3_PROFILE
@@ -316,11 +347,11 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                         if (P.sample_lights && S.n_lights > 0 && !m.skip_light_sampling) {
                             // next-event estimation, Camera.cpp:137-155: pick the light point now (4 draws)
                             const d3 gn = ld3(tri_at<PAD>(S, (uint32_t)sh_tri)->n);
-                            const d3 fn = dot(rd, gn) < 0. ? gn : -gn;
+                            const d3 fn = dot(rd, gn) < RL(0.) ? gn : -gn;
                             const LightPick lp = sample_lights<LLDS>(S, tr.o, rng, lds_lights, P.light_lds, lds_ltris, P.ltri_lds);
-                            double dist;
+                            real dist;
                             const d3 ldir = normalize_len(lp.pos - tr.o, dist);
-                            if (dot(fn, ldir) > 0.0 && lp.front) {
+                            if (dot(fn, ldir) > RL(0.0) && lp.front) {
                                 ltri = lp.tri;
                                 ldist = dist;
                                 tr.d = ldir;
@@ -332,7 +363,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 }
             } else if (state == ST_SHADOW) {
                 // ---- shadow ray returned: visibility = closest hit no nearer than dist - 1e-3 (Camera.cpp:152-155)
-                const double dist = ldist;
+                const real dist = ldist;
                 // The shadow ray was traced over [0.001, dist - 0.001] only: the reference's test
                 // `dist - |ps - pNearest| < 0.001` on the closest hit of [0.001, DBL_MAX) (|direction| = 1, so the distance
                 // IS t) fails exactly when some triangle is hit inside that interval; an escaping ray counts as unoccluded (B9)
@@ -342,7 +373,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     const ShadeCtx c = make_ctx<FEAT, PAD>(S, rd, tr.hit.alpha, tr.hit.beta, sh_tri);
                     const DMaterial& m = MATERIAL(c.material);
                     d3 ln0;
-                    double pdf;
+                    real pdf;
                     int32_t lmat;
                     if (LLDS && P.ltri_lds > 0) {
                         const DLightTri* lt = lds_ltris + ltri;
@@ -352,7 +383,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                         ln0 = ld3(lt->n); pdf = lt->pdf; lmat = lt->material;   // Triangle.cpp:92, BVH.cpp:91,66
                     }
                     // SetFaceNormal(Ray(origin, p - origin), normal) (Triangle.cpp:89-90); p - origin = tr.d * dist
-                    const d3 ln = dot(tr.d, ln0) < 0. ? ln0 : -ln0;
+                    const d3 ln = dot(tr.d, ln0) < RL(0.) ? ln0 : -ln0;
                     const d3 emission = ld3(MATERIAL(lmat).emission);
                     const d3 wo = world_to_local(-rd, c.f);
                     const d3 lwi = world_to_local(tr.d, c.f);
@@ -361,11 +392,11 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                         have_fr = m.type == 0; // Lambertian: Eval returned albedo / pi, which Scatter needs again
                         fr_seen = fr;
                     }
-                    const double cosT = lwi.z;
+                    const real cosT = lwi.z;
                     // cosThetaB = dot(WorldToLocal(lightNormal), -wi) (Camera.cpp:166-170): the shading frame is
                     // orthonormal (tangent in the triangle's plane, bitangent = t x n), so the local dot product IS the
                     // world one — three multiplies instead of a third change of basis; differs by rounding only
-                    const double cosTB = -dot(ln, tr.d);
+                    const real cosTB = -dot(ln, tr.d);
                     // Camera.cpp:172: emission*fr*cosT*cosTB/dist^2/pdf, the scalar factor folded into one division
                     const d3 direct = (emission * fr) * fast_div(cosT * cosTB, (dist * dist) * pdf);
                     ADD_RADIANCE(direct);
@@ -388,7 +419,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                             const d3 beta = (PST_LD(S_BETA) * att) * P.inv_rr;
                             PST_ST(S_BETA, beta);
                             // a zero throughput (Phong bad sample) contributes exactly 0 from here on
-                            if (!(beta.x == 0. && beta.y == 0. && beta.z == 0.)) {
+                            if (!(beta.x == RL(0.) && beta.y == RL(0.) && beta.z == RL(0.))) {
                                 tr.d = wi;
                                 prev_skip = m.skip_light_sampling != 0;
                                 first = false;
@@ -405,9 +436,9 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 if (s < s_end) state = ST_NEW_SAMPLE;
                 else {
                     double* o = partial + (size_t)item * 3;
-                    o[0] = acc.x;
-                    o[1] = acc.y;
-                    o[2] = acc.z;
+                    o[0] = (double)acc.x; // the partial sums are fp64 in either mode (K5 adds them in fp64)
+                    o[1] = (double)acc.y;
+                    o[2] = (double)acc.z;
                     state = ST_FETCH;
                 }
             }
@@ -464,10 +495,10 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
             if (state == ST_NEW_SAMPLE) {
                 // per-sample stream keyed (seed, j*W+i, s); Camera::GetRay (Camera.cpp:108-117): pixel centre, no jitter
                 rng.seed(P.seed, (uint64_t)py * (uint64_t)C.width + (uint64_t)px, (uint64_t)s);
-                double fx = (double)px, fy = (double)py;
+                real fx = (real)px, fy = (real)py;
                 if (P.jitter) { // the disabled SampleSquare() offset of Camera.cpp:110-111, drawn per sample: y first (g++ argument order)
-                    fy += rng.next() - 0.5;
-                    fx += rng.next() - 0.5;
+                    fy += rng.next() - RL(0.5);
+                    fx += rng.next() - RL(0.5);
                 }
                 const d3 ps = ld3(C.pixel00) + fx * ld3(C.du) + fy * ld3(C.dv);
                 tr.o = ld3(C.center);
@@ -491,7 +522,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 const bool sh_ray = state == ST_SHADOW;
                 n_closest += sh_ray ? 0u : 1u;
                 n_shadow += sh_ray ? 1u : 0u;
-                tr.start(S, sh_ray ? 0.001 : 0.0001, sh_ray ? ldist - 0.001 : PRT_INF);
+                tr.start(S, sh_ray ? RL(0.001) : RL(0.0001), sh_ray ? ldist - RL(0.001) : PRT_INF);
             }
         }
         PROF_MARK(4); // traversal set-up
@@ -500,7 +531,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
         // ---------------- traversal steps until enough lanes have finished to be worth refilling
         do {
             // the interval's lower end and the any-hit rule follow from the kind of ray: not kept as traversal state
-            tr.template round<COUNT>(S, stk, wc, P.leaf_batch, P.inner_min, state == ST_SHADOW ? 0.001 : 0.0001, state == ST_SHADOW);
+            tr.template round<COUNT>(S, stk, wc, P.leaf_batch, P.inner_min, state == ST_SHADOW ? RL(0.001) : RL(0.0001), state == ST_SHADOW);
         } while (wave_count(tr.active) > P.keep);
     }
 
@@ -544,6 +575,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
 #endif
 }
 
+#if !PRT_F32_TU
 // ------------------------------------------------------------------------------------------- K5
 // out[pixel] = sum over chunks (fixed order) of the item partial sums; pixels of other ranks' tiles
 // were zeroed by a memset so that the cross-rank sum is exact.
@@ -635,10 +667,12 @@ __global__ void k_tonemap(const float* __restrict__ in, size_t n, uint8_t* __res
     out[i] = (uint8_t)(sv * 255);
 }
 
+#endif // !PRT_F32_TU
+
 } // namespace
 
 // ------------------------------------------------------------------------------------------- launchers
-namespace prt {
+namespace PRT_NS {
 
 // The compiled permutations: lean, textures only, Phong only, CookTorrance only, everything.  A scene gets the smallest one
 // that covers its materials.
@@ -647,12 +681,15 @@ int render_permutation(int feat) {
     return PRT_FEAT_ALL;
 }
 
-// Light-tree nodes (16 bytes each) that fit in LDS next to the traversal stacks without costing a resident block:
-// 160 KB per CU, 32.8 KB of stacks per block, 3 blocks (lean / textured) or 2 (Phong / all).
-// Bytes of dynamic LDS a block may use without costing a resident block: 160 KB per CU, 32832 B static per block.
-int render_lds_budget(int feat) {
-    const int blocks = render_waves(render_permutation(feat)); // 4 waves per block, 4 SIMDs per CU: blocks per CU = waves per SIMD
-    return ((160 * 1024 / blocks - (int)sizeof(uint32_t) * PRT_STACK_DEPTH * PRT_BLOCK - 128) / 512) * 512; // 48640 / 21504 / 7680
+// Bytes of LDS a block may spend on shading tables next to its traversal stacks without costing a resident block:
+// 160 KB per CU, `blocks` resident blocks (4 waves per block, 4 SIMDs per CU: blocks per CU = waves per SIMD).
+int render_lds_budget(int feat, int stack_depth) {
+    int blocks = render_waves(render_permutation(feat));
+    if (PRT_F32_TU && stack_depth <= 32) blocks = 4; // fp32: registers allow a fourth wave per SIMD when the stacks do
+    return ((160 * 1024 / blocks - (int)sizeof(uint32_t) * stack_depth * PRT_BLOCK - 128) / 512) * 512;
+}
+size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds) {
+    return (size_t)light_lds * sizeof(DLightNode) + (size_t)mat_lds * sizeof(DMaterial) + (size_t)ltri_lds * sizeof(DLightTri);
 }
 
 typedef void (*RenderKernel)(DScene, DCamera, DRenderParams, double*, DCounters*);
@@ -676,9 +713,12 @@ static RenderKernel render_kernel(bool count, int feat, bool llds, bool pad) {
     return pad ? render_kernel_pad<true>(count, feat, llds) : render_kernel_pad<false>(count, feat, llds);
 }
 
-int render_blocks_per_cu(bool count, int feat, size_t dyn_lds) {
+static size_t stack_bytes(int stack_depth) { return PRT_DYN_STACK ? (size_t)PRT_BLOCK * stack_depth * sizeof(uint32_t) : 0; }
+
+int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth) {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel(count, feat, dyn_lds != 0, false), PRT_BLOCK, dyn_lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel(count, feat, table_bytes != 0, false), PRT_BLOCK,
+                                                                table_bytes + stack_bytes(stack_depth));
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
@@ -689,7 +729,7 @@ void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hit
     size_t want = (n + PRT_BLOCK - 1) / PRT_BLOCK;
     const size_t per_cu = std::max<size_t>(1, (160u * 1024u) / (sizeof(uint32_t) * PRT_STACK_DEPTH * PRT_BLOCK)); // LDS stacks per CU
     unsigned grid = (unsigned)std::min<size_t>(want, (size_t)n_cu * per_cu);
-    const bool pad = S.tri_stride == 128u && sizeof(DTri) != 128;
+    const bool pad = S.tri_stride == PRT_TRI_PAD_STRIDE(real) && sizeof(DTri) != PRT_TRI_PAD_STRIDE(real);
     auto k = count ? (pad ? k_trace_closest<true, true> : k_trace_closest<true, false>)
                    : (pad ? k_trace_closest<false, true> : k_trace_closest<false, false>);
     hipLaunchKernelGGL(k, dim3(grid), dim3(PRT_BLOCK), 0, st, S, d_rays, n, d_hits, d_ctr);
@@ -698,12 +738,59 @@ void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hit
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
                    bool count, int feat, unsigned grid, hipStream_t st) {
     static_assert(sizeof(DMaterial) % 16 == 0, "materials are staged in 16-byte pieces");
-    const size_t dyn_lds = (size_t)P.light_lds * sizeof(DLightNode) + (size_t)P.mat_lds * sizeof(DMaterial) +
-                           (size_t)P.ltri_lds * sizeof(DLightTri);
-    const bool pad = S.tri_stride == 128u && sizeof(DTri) != 128;
-    hipLaunchKernelGGL(render_kernel(count, feat, dyn_lds != 0, pad), dim3(grid), dim3(PRT_BLOCK), dyn_lds, st, S, C, P, d_partial, d_ctr);
+    const size_t tables = render_table_bytes(P.light_lds, P.mat_lds, P.ltri_lds);
+    const size_t dyn_lds = tables + stack_bytes(P.stack_depth);
+    const bool pad = S.tri_stride == PRT_TRI_PAD_STRIDE(real) && sizeof(DTri) != PRT_TRI_PAD_STRIDE(real);
+    hipLaunchKernelGGL(render_kernel(count, feat, tables != 0, pad), dim3(grid), dim3(PRT_BLOCK), dyn_lds, st, S, C, P, d_partial, d_ctr);
 }
 
+#if PRT_F32_TU
+// ------------------------------------------------------------------------------------------- fp64 -> fp32 tables
+// The fp32 records are derived on the device from the resident fp64 ones (which are already in BVH leaf order for
+// either builder): one thread per record, each value rounded to nearest.
+namespace {
+__global__ void k_convert_tris(const char* __restrict__ in, uint32_t in_stride, uint32_t n, char* __restrict__ out, uint32_t out_stride) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* a = reinterpret_cast<const double*>(in + (size_t)i * in_stride);
+    float4* o = reinterpret_cast<float4*>(out + (size_t)i * out_stride);
+    static_assert(sizeof(DTriT<double>) % 32 == 0 && sizeof(DTriT<float>) * 2 == sizeof(DTriT<double>), "same fields, half the size");
+    for (uint32_t k = 0; k < sizeof(DTriT<float>) / 16; ++k)
+        o[k] = make_float4((float)a[4 * k], (float)a[4 * k + 1], (float)a[4 * k + 2], (float)a[4 * k + 3]);
+}
+__global__ void k_convert_shade(const DTriShadeT<double>* __restrict__ in, uint32_t n, DTriShadeT<float>* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const DTriShadeT<double> a = in[i];
+    DTriShadeT<float> o;
+    for (int k = 0; k < 3; ++k) o.tangent[k] = (float)a.tangent[k];
+    for (int k = 0; k < 2; ++k) {
+        o.uv0[k] = (float)a.uv0[k];
+        o.uv1[k] = (float)a.uv1[k];
+        o.uv2[k] = (float)a.uv2[k];
+    }
+    o.material = a.material;
+    o.prim = a.prim;
+    o.pad[0] = 0.f;
+    out[i] = o;
+}
+__global__ void k_convert_reals(const double* __restrict__ in, size_t n, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+} // namespace
+void launch_convert_tris(const void* in, uint32_t in_stride, uint32_t n, void* out, uint32_t out_stride, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_convert_tris, dim3((n + 255) / 256), dim3(256), 0, st, static_cast<const char*>(in), in_stride, n, static_cast<char*>(out), out_stride);
+}
+void launch_convert_shade(const DTriShadeT<double>* in, uint32_t n, DTriShadeT<float>* out, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_convert_shade, dim3((n + 255) / 256), dim3(256), 0, st, in, n, out);
+}
+void launch_convert_reals(const double* in, size_t n, float* out, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_convert_reals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, in, n, out);
+}
+#endif // PRT_F32_TU
+
+#if !PRT_F32_TU
 void launch_finalize(const DCamera& C, const DRenderParams& P, const double* d_partial, double* d64, float* d32,
                      hipStream_t st) {
     unsigned grid = (unsigned)((P.items_per_chunk + 255) / 256);
@@ -738,5 +825,6 @@ void launch_tonemap(const float* d_in, size_t n, uint8_t* d_out, hipStream_t st)
     if (n == 0) return;
     hipLaunchKernelGGL(k_tonemap, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_in, n, d_out);
 }
+#endif // !PRT_F32_TU
 
-} // namespace prt
+} // namespace PRT_NS

@@ -9,8 +9,19 @@
 //   DMaterial[n_mat]          material table (Material.h parameters)
 //   DLightNode/DLightTri      the reference's area-CDF light tree (BVH.cpp:86-100), exact fp64 areas
 //   texels_lin / DTexture     per-texel GetPixel() result (3 doubles, sRGB->linear applied on the host) + descriptors
+//
+// Precision: the records that carry real numbers are templates over the scalar type R.  `double` is the reference's
+// arithmetic (glm::dvec3 everywhere) and what every host-side builder fills in; `float` is the layout of the fp32 fast
+// mode (PRT_PRECISION_F32: half the bytes and registers, tolerance tier 2), derived from the fp64 arrays on the
+// device.  A translation unit sees the un-suffixed names (DTri, DScene, ...) instantiated for PRT_REAL (default
+// double); prt_kernels_f32.hip compiles the same kernels with PRT_REAL = float.
 #pragma once
 #include <stdint.h>
+
+#ifndef PRT_REAL
+#define PRT_REAL double
+#endif
+typedef PRT_REAL prt_real;
 
 #ifndef PRT_BVH_WIDTH
 #define PRT_BVH_WIDTH 4      // children per node: 4 (64-byte nodes, collapsed from the binary tree; measured +11...32 %) or 2 (32-byte nodes)
@@ -21,6 +32,8 @@
                              // spends up to three entries per level, so on deep trees the budget decides how wide the nodes get:
                              // 8M-triangle soup 4.73M -> 3.77M nodes, 44.9 -> 36.0 visits per ray, +21 % (32 -> 40); 48 costs K1 a wave
 #endif
+#define PRT_STACK_SHALLOW 32 // a launch whose tree needs at most this many entries gets 32 KB of stacks per block: room for a
+                             // fourth block per CU, which the fp32 render kernels have the registers for
 #define PRT_BVH2_LEVELS 30   // inner-node levels of the binary tree both builders bound their trees to
 #ifndef PRT_LEAF_MAX
 #define PRT_LEAF_MAX 4       // triangles per BVH leaf (leaf ref stores count-1 in 3 bits)
@@ -77,108 +90,131 @@ static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
 // In HBM the records sit DScene::tri_stride bytes apart: 96 (packed) for scenes the caches hold, 128 (one record per
 // 128-byte line, none straddling two) for scenes that stream from HBM — measured: packed +3 % on the cornell frame,
 // padded +6 % on the 8M-triangle soup.
-struct alignas(32) DTri {
-    double n[3];   // unit geometric normal        (Triangle.cpp:19)
-    double D;      // dot(normal, v0)              (Triangle.cpp:50)
-    double A[3], a0;
-    double B[3], b0;
+template <typename R>
+struct alignas(4 * sizeof(R)) DTriT {
+    R n[3];   // unit geometric normal        (Triangle.cpp:19)
+    R D;      // dot(normal, v0)              (Triangle.cpp:50)
+    R A[3], a0;
+    R B[3], b0;
 };
-static_assert(sizeof(DTri) == 96, "DTri must be 96 bytes");
+typedef DTriT<prt_real> DTri;
+static_assert(sizeof(DTriT<double>) == 96 && sizeof(DTriT<float>) == 48, "DTri must be 96 / 48 bytes");
 #else
-struct alignas(128) DTri {
-    double n[3];   // unit geometric normal        (Triangle.cpp:19)
-    double D;      // dot(normal, v0)              (Triangle.cpp:50)
-    double w[3];   // n / dot(n,n), n = e0 x e1    (Triangle.cpp:51)
-    double v0[3];
-    double e0[3];  // v1 - v0
-    double e1[3];  // v2 - v0
+template <typename R>
+struct alignas(16 * sizeof(R)) DTriT {
+    R n[3];   // unit geometric normal        (Triangle.cpp:19)
+    R D;      // dot(normal, v0)              (Triangle.cpp:50)
+    R w[3];   // n / dot(n,n), n = e0 x e1    (Triangle.cpp:51)
+    R v0[3];
+    R e0[3];  // v1 - v0
+    R e1[3];  // v2 - v0
 };
-static_assert(sizeof(DTri) == 128, "DTri must be 128 bytes");
+typedef DTriT<prt_real> DTri;
+static_assert(sizeof(DTriT<double>) == 128, "DTri must be 128 bytes");
 #endif
 
-struct alignas(32) DTriShade {
-    double tangent[3]; // Triangle.cpp:31-46
-    double uv0[2], uv1[2], uv2[2];
+template <typename R>
+struct alignas(4 * sizeof(R)) DTriShadeT {
+    R tangent[3]; // Triangle.cpp:31-46
+    R uv0[2], uv1[2], uv2[2];
     int32_t material;
     int32_t prim;      // index in PrtSceneDesc order
-    double pad[2];
+    R pad[sizeof(R) == 8 ? 2 : 1];
 };
-static_assert(sizeof(DTriShade) == 96, "DTriShade must be 96 bytes");
+typedef DTriShadeT<prt_real> DTriShade;
+static_assert(sizeof(DTriShadeT<double>) == 96 && sizeof(DTriShadeT<float>) == 48, "DTriShade must be 96 / 48 bytes");
 
-struct DMaterial {
+template <typename R>
+struct alignas(16) DMaterialT {
     int32_t type;
     int32_t texture;
-    double kd[3], ks[3];
-    double ns, pkd, pks;
-    double emission[3]; // GetEmission(): DiffuseLight radiance / Debug albedo
-    double eta[3], k[3];
-    double alpha_x, alpha_y;
+    R kd[3], ks[3];
+    R ns, pkd, pks;
+    R emission[3]; // GetEmission(): DiffuseLight radiance / Debug albedo
+    R eta[3], k[3];
+    R alpha_x, alpha_y;
     int32_t has_emission, skip_light_sampling;
-    double inv_ns1, spec_scale; // Phong: 1 / (Ns + 1) and (Ns + 2) / (Ns + 1), divided once on the host
+    R inv_ns1, spec_scale; // Phong: 1 / (Ns + 1) and (Ns + 2) / (Ns + 1), divided once on the host
 };
+typedef DMaterialT<prt_real> DMaterial;
+static_assert(sizeof(DMaterialT<double>) == 192 && sizeof(DMaterialT<float>) % 16 == 0, "materials are staged into LDS in 16-byte pieces");
 
 struct DTexture {
     int32_t width, height, channels, has_data;
     uint64_t offset; // index of the texture's first double in texels_lin
 };
 
-struct DLightNode {
-    double left_area;   // GetArea() of the left child (BVH.cpp:93-97)
+template <typename R>
+struct alignas(16) DLightNodeT {
+    R left_area;   // GetArea() of the left child (BVH.cpp:93-97)
     int32_t left, right; // >=0 node, <0: ~index into light tris
 };
+typedef DLightNodeT<prt_real> DLightNode;
+static_assert(sizeof(DLightNodeT<double>) == 16 && sizeof(DLightNodeT<float>) == 16, "light nodes are 16 bytes");
 
-struct alignas(128) DLightTri {
-    double v0[3], v1[3], v2[3];
-    double n[3];
-    double area;
+template <typename R>
+struct alignas(sizeof(R) == 8 ? 128 : 16) DLightTriT {
+    R v0[3], v1[3], v2[3];
+    R n[3];
+    R area;
     int32_t material, prim;
-    double pdf;    // (1/area)*area/total_area evaluated in that order on the host (Triangle.cpp:92, BVH.cpp:91,66)
-    double pad;
+    R pdf;    // (1/area)*area/total_area evaluated in that order on the host (Triangle.cpp:92, BVH.cpp:91,66)
+    R pad;
 };
-static_assert(sizeof(DLightTri) == 128, "DLightTri must be 128 bytes");
+typedef DLightTriT<prt_real> DLightTri;
+static_assert(sizeof(DLightTriT<double>) == 128 && sizeof(DLightTriT<float>) % 16 == 0, "DLightTri must be 128 bytes (fp64); staged in 16-byte pieces");
 
-struct DScene {
+template <typename R>
+struct DSceneT {
     const DNode* nodes;
-    const DTri* tris;
-    const DTriShade* shade;
-    const DMaterial* materials;
+    const DTriT<R>* tris;
+    const DTriShadeT<R>* shade;
+    const DMaterialT<R>* materials;
     const DTexture* textures;
-    const double* texels_lin; // linearised texels, 3 doubles each: GetPixel() of Texture.cpp:50-65 evaluated on the host
-    const DLightNode* light_nodes;
-    const DLightTri* light_tris;
+    const R* texels_lin; // linearised texels, 3 reals each: GetPixel() of Texture.cpp:50-65 evaluated on the host
+    const DLightNodeT<R>* light_nodes;
+    const DLightTriT<R>* light_tris;
     int32_t light_root; // ref into light tree; valid iff n_lights > 0
     int32_t n_lights;
-    double light_area;  // GetArea() of the top-level lights BVHNode
+    R light_area;  // GetArea() of the top-level lights BVHNode
     uint32_t n_nodes, n_tris;
     float coord_scale;  // largest |coordinate| of any BVH box (fp32, rounded up): bounds the slab-test rounding
     float pad_;
     float grid_origin[3]; // PRT_NODE16: box coordinate = grid_origin + q * grid_step
     float grid_step[3];
-    uint32_t tri_stride;  // bytes between consecutive DTri records (sizeof(DTri), or 128 for HBM-resident scenes)
+    uint32_t tri_stride;  // bytes between consecutive DTri records: sizeof(DTri), or the padded stride for HBM-resident scenes
     uint32_t pad2_;
 };
+typedef DSceneT<prt_real> DScene;
+// padded record stride: one fp64 record per 128-byte line, two fp32 records per line — never one straddling two lines
+#define PRT_TRI_PAD_STRIDE(R) (sizeof(DTriT<R>) <= 48 ? 64u : 128u)
 #define PRT_TRI_PADDED_ABOVE (256ull << 20) // triangle bytes beyond which records are padded to 128 bytes (Infinity Cache size)
 
 // camera state after Camera::Initialize (Camera.cpp:75-106), computed on the host
-struct DCamera {
-    double center[3], pixel00[3], du[3], dv[3];
+template <typename R>
+struct DCameraT {
+    R center[3], pixel00[3], du[3], dv[3];
     int32_t width, height;
 };
+typedef DCameraT<prt_real> DCamera;
 
-struct DRenderParams {
+template <typename R>
+struct DRenderParamsT {
     int32_t spp, max_depth, sample_lights, chunks;
-    double rr, inv_rr;
-    double background[3];
+    R rr, inv_rr;
+    R background[3];
     uint64_t seed;
     int32_t tile, tiles_x, tiles_y, n_tiles;
     int32_t rank, nranks, owned_tiles, jitter; // jitter: per-sample SampleSquare pixel offset (Camera.cpp:110-111)
     int32_t keep, leaf_batch, inner_min, scramble;
     int32_t light_lds, mat_lds; // LLDS kernels: light-tree nodes / materials staged in (dynamic) LDS by K3
-    int32_t ltri_lds, pad4;     // ... and ALL light triangles (n_lights) when there are at most 32 of them, else 0 // wave scheduling thresholds of K3 (see prt_kernels.hip)
+    int32_t ltri_lds;           // ... and ALL light triangles (n_lights) when there are at most 32 of them, else 0
+    int32_t stack_depth;        // LDS traversal stack entries per lane of this launch (dynamic LDS): PRT_STACK_DEPTH, or less for a tree that needs less
     uint64_t items_per_chunk; // owned_tiles * tile * tile
     uint64_t n_items;         // items_per_chunk * chunks
     int32_t chunk_begin[PRT_MAX_CHUNKS + 1]; // chunk c covers samples [chunk_begin[c], chunk_begin[c+1])
 };
+typedef DRenderParamsT<prt_real> DRenderParams;
 
 // K3 deals its work items from PRT_ITEM_QUEUES counters instead of one: a single address takes ~90 returning
 // atomics per microsecond, which the short items at the end of a launch (and every launch at low spp) exceed.

@@ -108,6 +108,7 @@ static int check_tree(const BuiltBVH& b, const std::vector<HostTri>& tris) {
 int main() {
     std::mt19937_64 rng(99);
     std::uniform_real_distribution<double> U(0.0, 1.0);
+    int n_shallow = 0;
     for (int round = 0; round < 5; ++round) {
         const size_t n = round == 0 ? 1 : round == 1 ? 2 : round == 2 ? 37 : round == 3 ? 5000 : 60000;
         std::vector<double> v(n * 9), uv(n * 6), nr(n * 9, 0.0);
@@ -156,11 +157,25 @@ int main() {
         if (b.order.size() != n) return fail("order size");
         if (check_tree(b, tris)) return 1;
         if (!validate_nodes(b.nodes.data(), b.nodes.size(), n, &err)) return fail(err.c_str());
+#if PRT_BVH_WIDTH == 4
+        // the second collapse (small LDS stacks, fp32 render kernels): present exactly when the first one can need more
+        // than PRT_STACK_SHALLOW entries, a well-formed tree over the same leaves, and within that bound itself
+        if (b.stack_need != tree_stack_need(b.nodes.data(), b.nodes.size())) return fail("stack_need is not the tree's");
+        if ((b.stack_need > PRT_STACK_SHALLOW) != !b.nodes_shallow.empty()) return fail("shallow tree present / absent wrongly");
+        if (!b.nodes_shallow.empty()) {
+            BuiltBVH sh = b;
+            sh.nodes = b.nodes_shallow;
+            if (check_tree(sh, tris)) return fail("shallow tree fails the structural check");
+            if (!validate_nodes(sh.nodes.data(), sh.nodes.size(), n, &err)) return fail(err.c_str());
+            if (tree_stack_need(sh.nodes.data(), sh.nodes.size()) > PRT_STACK_SHALLOW) return fail("shallow tree needs more than its budget");
+            ++n_shallow;
+        }
+#endif
         std::vector<double> moved(v);
         for (double& x : moved) x = x * 1.5 + 0.25;
         update_triangles(moved.data(), nullptr, tris);
         if (!build_bvh(tris, b, &err) || check_tree(b, tris)) return fail("rebuild after update_triangles");
-        std::printf("n=%zu nodes=%zu depth=%u lights=%zu ok\n", n, b.nodes.size(), b.depth, lt.tris.size());
+        std::printf("n=%zu nodes=%zu depth=%u need=%d shallow=%zu lights=%zu ok\n", n, b.nodes.size(), b.depth, b.stack_need, b.nodes_shallow.size(), lt.tris.size());
     }
     return 0;
 }

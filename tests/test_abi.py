@@ -171,7 +171,7 @@ def test_alternative_build_configurations_still_compile(flags):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not installed")
     csrc = os.path.join(ROOT, "pooraytracer_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("prt_kernels.hip", "bvh_build_gpu.hip", "bvh_build.cpp", "prt_api.cpp")]
+    srcs = [os.path.join(csrc, f) for f in ("prt_kernels.hip", "prt_kernels_f32.hip", "bvh_build_gpu.hip", "bvh_build.cpp", "prt_api.cpp")]
     r = subprocess.run([hipcc, "-std=c++17", "--offload-arch=gfx950", "-fsyntax-only", "-Wno-unused-function"] + flags + srcs,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
