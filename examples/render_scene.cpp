@@ -59,6 +59,7 @@ int main(int argc, char** argv) {
         camera.up = vec3(v[6], v[7], v[8]);
         if (argc > 6) camera.SetViewParametersByXmlFile(argv[6]);
         // additions of this build, driven from the environment so the argument list stays main.cpp-like
+        if (const char* e = std::getenv("PRT_EXAMPLE_F32")) camera.bFloatPrecision = std::atoi(e) != 0; // fp32 fast mode
         if (const char* e = std::getenv("PRT_EXAMPLE_DEVICES")) { // e.g. "0,1,2,3": tiles over several GPUs
             for (const char* q = e; *q;) {
                 camera.devices.push_back(std::atoi(q));

@@ -37,6 +37,7 @@ public:
     // additions (not in the reference): RNG key, device index, counters of the last Render
     unsigned long long seed = 1;
     bool bBuildBvhOnDevice = false; // PRT_SCENE_DEVICE_BVH: build the traversal BVH on the GPU (first Render of a world)
+    bool bFloatPrecision = false; // PRT_PRECISION_F32: the fp32 fast mode (tolerance tier 2; the reference computes in double)
     bool bPixelJitter = false; // per-sample SampleSquare() pixel offset: the AA the reference has commented out (Camera.cpp:110-111)
     int device = 0;
     std::vector<int> devices; // non-empty: cut the frame into tiles over these GPUs (one host thread each); overrides `device`

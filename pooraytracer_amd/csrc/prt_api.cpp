@@ -640,6 +640,8 @@ static int ensure_f32(PrtScene* s) {
             need = prt::tree_stack_need(hn.data(), hn.size());
         }
         s->stack_depth32 = need <= PRT_STACK_SHALLOW ? PRT_STACK_SHALLOW : PRT_STACK_DEPTH;
+        if (const char* e = std::getenv("PRT_TUNE_STACK32")) s->stack_depth32 = std::max(need, std::min(PRT_STACK_DEPTH, std::atoi(e))); // developer: smaller stacks when the tree allows
+        if (std::getenv("PRT_TUNE_VERBOSE")) std::fprintf(stderr, "[prt] fp32 tables: tree needs %d stack entries, using %d\n", need, s->stack_depth32);
     }
     size_tables(s, prt32::render_lds_budget(s->feat, s->stack_depth32), sizeof(DMaterialT<float>), sizeof(DLightTriT<float>),
                 sizeof(DLightNodeT<float>), &s->mat_lds32, &s->ltri_lds32, &s->light_lds32);

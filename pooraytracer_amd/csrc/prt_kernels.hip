@@ -685,7 +685,7 @@ int render_permutation(int feat) {
 // 160 KB per CU, `blocks` resident blocks (4 waves per block, 4 SIMDs per CU: blocks per CU = waves per SIMD).
 int render_lds_budget(int feat, int stack_depth) {
     int blocks = render_waves(render_permutation(feat));
-    if (PRT_F32_TU && stack_depth <= 32) blocks = 4; // fp32: registers allow a fourth wave per SIMD when the stacks do
+    if (PRT_F32_TU && stack_depth <= 32) blocks = PRT_F32_WAVES > 4 && stack_depth <= 24 ? 5 : 4; // fp32: registers allow a fourth wave per SIMD when the stacks do
     return ((160 * 1024 / blocks - (int)sizeof(uint32_t) * stack_depth * PRT_BLOCK - 128) / 512) * 512;
 }
 size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds) {

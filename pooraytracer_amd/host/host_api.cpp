@@ -374,7 +374,7 @@ void Camera::Render(Hittable& world, Hittable& lights) {
     p.max_depth = maxDepth;
     p.russian_roulette = russianRoulette;
     p.sample_lights = bSampleLights ? 1 : 0;
-    p.precision = PRT_PRECISION_F64;
+    p.precision = bFloatPrecision ? PRT_PRECISION_F32 : PRT_PRECISION_F64;
     p.background[0] = background.x; p.background[1] = background.y; p.background[2] = background.z;
     p.seed = seed;
     p.tile_size = 32;

@@ -144,3 +144,22 @@ def test_f32_after_moving_geometry_and_bad_precision(gpu):
     assert abs(second.mean() - exact.mean()) <= 2e-3 * exact.mean()
     with pytest.raises(api.PrtError):
         sc.render(spp=1, precision=7)
+
+
+def test_f32_through_the_cpp_camera(gpu, tmp_path):
+    """Camera::bFloatPrecision (include/pooraytracer/Camera.h) selects the fp32 kernels: the main.cpp-style driver must
+    produce the frame the binding produces with precision=F32 (same C ABI, same inputs: bit-identical)."""
+    import os
+    import subprocess
+    from pooraytracer_amd import build
+    exe = build.build_host_example()
+    data = scenes.mixed_materials(40, 32)
+    dump = str(tmp_path / "scene.bin")
+    scenes.dump_scene(data, dump)
+    out = str(tmp_path / "out.f64")
+    r = subprocess.run([exe, dump, "6", "8", out], capture_output=True, text=True, timeout=300, env=dict(os.environ, PRT_EXAMPLE_F32="1"))
+    assert r.returncode == 0, r.stderr + r.stdout
+    img = np.fromfile(out, dtype=np.float64).reshape(32, 40, 3)
+    sc = api.Scene(data).upload(gpu)
+    assert np.array_equal(img, sc.render(spp=6, max_depth=8, seed=1, precision=F32))
+    assert not np.array_equal(img, sc.render(spp=6, max_depth=8, seed=1))

@@ -23,19 +23,25 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 kernel_key = "k_trace_closest<false" if workload.startswith("s") and "rays" in workload else "k_render<false"
+scene_key = "DSceneT<float>" if workload.endswith("-f32") else "DSceneT<double>"  # the fp32 workloads also render one fp64 frame (their parity check)
+
+
+def timed(name):
+    return kernel_key in name and scene_key in name
+
 
 ks = glob.glob(os.path.join(src, "trace", "**", "*_kernel_stats.csv"), recursive=True)
 stats = {}
 if ks:
     shutil.copy(ks[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
     for row in csv.DictReader(open(ks[0])):
-        if kernel_key in row["Name"]:
+        if timed(row["Name"]):
             stats = {"calls": int(row["Calls"]), "avg_ns": float(row["AverageNs"]), "name": row["Name"]}
 pmc = {}
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*_counter_collection.csv"), recursive=True):
     per = {}
     for row in csv.DictReader(open(f)):
-        if kernel_key not in row["Kernel_Name"]:
+        if not timed(row["Kernel_Name"]):
             continue
         per.setdefault(row["Counter_Name"], {}).setdefault(row["Dispatch_Id"], 0.0)
         per[row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
