@@ -58,6 +58,7 @@ WORKLOADS = {
     "cornell-box-f32": ("cornell_box", {}, 500, 20, 1),
     "veach-mis-f32": ("veach_mis", {}, 3000, 100, 1),
     "bathroom2-f32": ("bathroom", {}, 100, 50, 1),
+    "bathroom2-spp500-f32": ("bathroom", {}, 500, 50, 1),
 }
 # K1 closest-hit microbenchmarks: 2^24 seeded incoherent rays resident in HBM
 RAY_WORKLOADS = {
@@ -459,6 +460,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cornell-box", choices=sorted(WORKLOADS) + sorted(RAY_WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override spp (0 = the workload's)")
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
+                    help="f64 = the reference's arithmetic (default, the headline); f32 = the fp32 fast mode of the same workload (tolerance tier 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="headline workload only (no `workloads` / `config5` entries)")
     ap.add_argument("--no-pipeline", action="store_true", help="one stream, one framebuffer: frames strictly back to back")
@@ -467,6 +470,10 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
 
+    if args.precision == "f32" and not args.workload.endswith("-f32"):
+        if args.workload + "-f32" not in WORKLOADS:
+            raise SystemExit(f"--precision f32: no fp32 variant of {args.workload}")
+        args.workload += "-f32"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus)  # does not return
     rank = int(os.environ.get("RANK", "0"))
@@ -530,11 +537,11 @@ def main():
     else:
         w = time_render(ctx, args.workload, args.steps, args.warmup, spp_override=args.spp)
         extras, config5 = [], None
-        if not args.no_extra and args.workload == "cornell-box" and args.spp == 0:
+        if not args.no_extra and args.workload in ("cornell-box", "cornell-box-f32") and args.spp == 0:
             if nranks > 1:
                 # BASELINE config 5: bathroom2 spp 500 depth 50, tiles over the ranks + RCCL reduce
-                config5 = time_render(ctx, "bathroom2-spp500", max(1, min(args.steps, 3)), 1, with_cpu=False)
-            else:
+                config5 = time_render(ctx, "bathroom2-spp500" + ("-f32" if args.precision == "f32" else ""), max(1, min(args.steps, 3)), 1, with_cpu=False)
+            elif args.precision == "f64":
                 for name in EXTRA_AT_N1:
                     if name in RAY_WORKLOADS:
                         extras.append(time_rays(ctx, name, 5, 1))
@@ -553,7 +560,7 @@ def main():
                 "higher_is_better": True,
                 "scaling": "strong",
                 "vs_baseline": None,
-                "dtype": "f64",
+                "dtype": w["dtype"],
                 "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo)" if rehearsal else ""),
                 "config": {
                     "workload": w["config"],
