@@ -163,3 +163,22 @@ def test_f32_through_the_cpp_camera(gpu, tmp_path):
     sc = api.Scene(data).upload(gpu)
     assert np.array_equal(img, sc.render(spp=6, max_depth=8, seed=1, precision=F32))
     assert not np.array_equal(img, sc.render(spp=6, max_depth=8, seed=1))
+
+
+def test_f32_render_options_follow_the_fp64_kernels(gpu):
+    """Every switch of PrtRenderParams means the same thing in either precision: depth 0, no NEE, a background colour,
+    Russian roulette 1.0, pixel jitter, explicit sample chunks — compared with the fp64 kernels' frame of the same seeds
+    (which test_gpu_parity.py holds against the oracle)."""
+    data = scenes.mixed_materials(48, 40)
+    sc = api.Scene(data).upload(gpu)
+    for kw in (dict(max_depth=0), dict(sample_lights=False, background=(0.2, 0.3, 0.5)), dict(rr=1.0, max_depth=4),
+               dict(pixel_jitter=True), dict(sample_chunks=3), dict(max_depth=-1)):
+        kw = dict(dict(spp=32, max_depth=8, seed=11), **kw)
+        a, b = sc.render(**kw), sc.render(precision=F32, **kw)
+        assert np.isfinite(b).all()
+        if a.mean() == 0.0:
+            assert b.mean() == 0.0
+            continue
+        assert abs(b.mean() - a.mean()) <= 2e-3 * a.mean(), kw
+        close = (np.abs(a - b) <= 1e-3 * np.maximum(1.0, np.abs(a))).all(-1)
+        assert close.mean() >= 0.95, (kw, float(close.mean()))
