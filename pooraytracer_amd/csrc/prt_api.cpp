@@ -546,8 +546,22 @@ int prt_scene_update_vertices(PrtScene* s, const double* vertices, const double*
 // fp32 fast mode: the float tables are derived from the resident fp64 ones the first time they are asked for
 // (synchronous; the scene then holds both).  Triangle and shading records and texels are converted on the device —
 // they already are in BVH leaf order there, whichever builder made the tree — the small tables on the host.
+static int ensure_f32_impl(PrtScene* s);
+// All or nothing, like the upload: a failure frees what this call allocated and leaves the scene without fp32 tables.
 static int ensure_f32(PrtScene* s) {
     if (s->f32_ready) return PRT_OK;
+    const size_t mark = s->allocs.size();
+    const int rc = ensure_f32_impl(s);
+    if (rc != PRT_OK) {
+        const std::string keep = g_err;
+        for (size_t i = mark; i < s->allocs.size(); ++i) (void)hipFree(s->allocs[i]);
+        s->allocs.resize(mark);
+        std::memset(&s->d32, 0, sizeof(s->d32));
+        g_err = keep;
+    }
+    return rc;
+}
+static int ensure_f32_impl(PrtScene* s) {
     const DScene& d = s->d;
     DSceneT<float>& f = s->d32;
     std::memset(&f, 0, sizeof(f));
