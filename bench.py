@@ -63,9 +63,10 @@ WORKLOADS = {
 # K1 closest-hit microbenchmarks: 2^24 seeded incoherent rays resident in HBM
 RAY_WORKLOADS = {
     "s0-rays-cornell": ("cornell_box", {}, False),                          # cache-resident geometry
+    "s0-rays-cornell-coherent": ("cornell_box", {}, False),                 # ... and camera rays in pixel order (SURVEY §8d "coherent")
     "s4-rays-soup8m": ("triangle_soup", {"n_tris": 8_000_000}, True),       # HBM-resident; tree built on the GPU
 }
-EXTRA_AT_N1 = ["veach-mis", "bathroom2", "cornell-ct", "s0-rays-cornell", "s4-rays-soup8m",
+EXTRA_AT_N1 = ["veach-mis", "bathroom2", "cornell-ct", "s0-rays-cornell", "s0-rays-cornell-coherent", "s4-rays-soup8m",
                "cornell-box-f32", "veach-mis-f32", "bathroom2-f32"]
 TOL = 1e-9  # per channel, relative to max(1, |x|): fp64 on both sides, differences = FMA contraction + libm ulps
 
@@ -389,7 +390,8 @@ def time_rays(ctx, name, steps, warmup):
     info = sc.bvh_info()
     n = 1 << 24
     lo, hi = data.bounds()
-    rays_np = scenes.random_rays(n, lo, hi, seed=12345)
+    coherent = name.endswith("-coherent")
+    rays_np = scenes.camera_rays(data.camera, n, seed=12345) if coherent else scenes.random_rays(n, lo, hi, seed=12345)
     d_r = torch.from_numpy(rays_np.view(np.float64).reshape(-1, 8)).cuda()
     d_h = torch.zeros((n, 4), dtype=torch.float64, device="cuda")
     for _ in range(warmup):
@@ -410,7 +412,7 @@ def time_rays(ctx, name, steps, warmup):
     hits = d_h.cpu().numpy().view(np.dtype([("t", "<f8"), ("a", "<f8"), ("b", "<f8"), ("prim", "<i4"), ("front", "<i4")])).reshape(-1)
     out = {"workload": name, "value": round(n * steps / elapsed / 1e6, 2), "unit": "Mrays/s", "steps": steps, "warmup": warmup,
            "ms_per_step": round(elapsed / steps * 1e3, 3), "rays_per_launch": n,
-           "config": f"{name}: {n} seeded random rays vs {data.n_tris} triangles ({info['width']}-wide BVH, {info['n_nodes']} nodes, "
+           "config": f"{name}: {n} seeded {'camera rays in pixel order' if coherent else 'random rays'} vs {data.n_tris} triangles ({info['width']}-wide BVH, {info['n_nodes']} nodes, "
                      f"depth {info['depth']}, {'GPU' if info['built_on_device'] else 'host'} build, create+upload {build_s:.1f} s)",
            "hit_fraction": round(float((hits["prim"] >= 0).mean()), 4),
            "roofline": roofline(name, "k_trace_closest", bpr, npr, tpr, fpr, n, 0.0, sum(ms) / len(ms), "HIP events around each launch")}
@@ -524,7 +526,7 @@ def main():
         if nranks != 1:
             raise SystemExit("ray microbenchmarks are single-GPU")
         w = time_rays(ctx, args.workload, args.steps, args.warmup)
-        out = {"metric": "Mrays/s (closest-hit, incoherent rays)", "value": w["value"], "unit": "Mrays/s", "n_gpus": 1,
+        out = {"metric": "Mrays/s (closest-hit, %s rays)" % ("coherent camera" if args.workload.endswith("-coherent") else "incoherent"), "value": w["value"], "unit": "Mrays/s", "n_gpus": 1,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": w["ms_per_step"], "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": w["config"], "hit_fraction": w["hit_fraction"], "rays_per_launch": w["rays_per_launch"]},

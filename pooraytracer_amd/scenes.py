@@ -364,6 +364,34 @@ def random_rays(n, lo, hi, seed=12345, tmin=1e-4, tmax=np.inf):
     return rays
 
 
+def camera_rays(cam, n, seed=12345, tmin=1e-4, tmax=np.inf):
+    """Coherent rays (SURVEY.md §8d, S0 "coherent" variant): n primary rays of `cam` in pixel order — pixel k % (W*H),
+    jittered inside the pixel (uniform, seeded) so that repeated passes over the image are not identical rays.
+    Camera::Initialize / GetRay arithmetic (Camera.cpp:75-117), directions left unnormalised like the reference's."""
+    W, H = cam.width, cam.height
+    eye, look, up = (np.asarray(v, dtype=np.float64) for v in (cam.eye, cam.look_at, cam.up))
+    el = eye - look
+    focal = np.sqrt(el @ el)
+    vh = 2.0 * np.tan(np.radians(cam.fovy) / 2.0) * focal
+    vw = vh * (W / H)
+    w = el / focal
+    u = np.cross(up, w)
+    u /= np.sqrt(u @ u)
+    v = np.cross(w, u)
+    du, dv = vw * u / W, vh * (-v) / H
+    p00 = eye - focal * w - vw * u / 2.0 - vh * (-v) / 2.0 + 0.5 * (du + dv)
+    k = np.arange(n) % (W * H)
+    rng = np.random.default_rng(seed)
+    fx = (k % W) + rng.random(n) - 0.5
+    fy = (k // W) + rng.random(n) - 0.5
+    rays = np.zeros(n, dtype=_abi.RAY_DTYPE)
+    rays["o"] = eye
+    rays["d"] = p00 + fx[:, None] * du + fy[:, None] * dv - eye
+    rays["tmin"] = tmin
+    rays["tmax"] = tmax
+    return rays
+
+
 def tiny_scene() -> SceneData:
     """A 64x64 cornell with a coarse ball: the smoke / unit-test workload (runs in ms on the CPU)."""
     return cornell_box(ball_subdiv=1, width=64, height=64)
