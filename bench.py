@@ -347,6 +347,8 @@ def time_render(ctx, name, steps, warmup, spp_override=0, with_cpu=True, cpu_tar
         fb_bytes = 24.0 * cam.width * cam.height / nranks  # fp64 per-item partial sums written by K3
         out["roofline"] = roofline(name, "k_render", bpr, npr, tpr, fpr, rays_per_launch, fb_bytes, mean_ms, src)
         if precision:
+            out["note"] = ("fp32 fast mode (PRT_PRECISION_F32): an opt-in extra, NOT the headline — `value` of the JSON line and every "
+                           "1e-9 parity claim are fp64; this entry is checked at the second tolerance tier only")
             # tolerance tier 2: against the fp64 kernels' frame of the same seeds (itself checked against the oracle above)
             ref = torch.zeros((cam.height, cam.width, 3), dtype=torch.float64, device="cuda")
             got = torch.zeros_like(ref)
@@ -431,7 +433,8 @@ def time_rays(ctx, name, steps, warmup):
     both = (hits["prim"] >= 0) & (h32["prim"] >= 0)
     rel = np.abs(h32["t"][both] - hits["t"][both]) / np.maximum(1.0, hits["t"][both])
     flips = int(((hits["prim"] >= 0) != (h32["prim"] >= 0)).sum())
-    out["f32"] = {"value": round(n * steps / el32 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(el32 / steps * 1e3, 3),
+    out["f32"] = {"note": "fp32 fast mode of the same batch: an opt-in extra, not the workload's `value` (which is fp64)",
+                  "value": round(n * steps / el32 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(el32 / steps * 1e3, 3),
                   "kernel_ms": round(sum(ms32) / len(ms32), 3), "dtype": "f32",
                   "parity_check": {"against": "the fp64 kernel's hits", "hit_miss_flips": flips, "beyond_1e-5": int((rel > 1e-5).sum()),
                                    "rel_t_p999": float(np.quantile(rel, 0.999)) if rel.size else 0.0, "tolerance": "1e-5 for all but 1e-4 of the rays",
