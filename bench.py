@@ -80,13 +80,32 @@ def free_port():
     return p
 
 
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT torch or HIP (the launcher must not initialise a GPU runtime before it
+    starts its rank processes): the KFD topology nodes that have SIMDs, narrowed by HIP_/ROCR_/CUDA_VISIBLE_DEVICES.
+    None when the topology cannot be read — the ranks then fail by themselves if a device is missing."""
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        n = 0
+        for node in os.listdir(base):
+            for line in open(os.path.join(base, node, "properties")):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except Exception:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(n):
     """Start n rank processes of this script, one per GPU.  Nothing here initialises a GPU: the children do."""
     rehearsal = os.environ.get("PRT_BENCH_REHEARSAL") == "1"
     if not rehearsal and os.environ.get("PRT_BENCH_LAUNCH_STUB") != "1":
-        import torch
-        have = torch.cuda.device_count()  # counting devices does not initialise the GPU
-        if have < n:
+        have = visible_gpus()
+        if have is not None and have < n:
             raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible")
     port = str(free_port())
     procs = []

@@ -82,8 +82,9 @@ inline uint64_t mix64(uint64_t z) {
 struct Rng {
     uint64_t s;
     void seed(uint64_t seed, uint64_t pixel, uint64_t sample) {
-        // one finaliser over the whole key (Stafford's mix13 avalanches every input bit): pixel and sample are below 2^32
-        s = mix64((seed + 0x9E3779B97F4A7C15ULL) ^ ((pixel + 1) << 32) ^ (sample + 1));
+        // the seed is hashed on its own, then combined with (pixel, sample) and hashed again (Stafford's mix13 avalanches
+        // every input bit; pixel and sample are below 2^32): streams of different seeds are unrelated
+        s = mix64(mix64(seed + 0x9E3779B97F4A7C15ULL) ^ ((pixel + 1) << 32) ^ (sample + 1));
         if (s == 0) s = 0x9E3779B97F4A7C15ULL; // the all-zero state is the generator's fixed point
     }
     // RandomDouble(), RandomNumberGenerator.h:16-19: rand() / (RAND_MAX + 1.0), RAND_MAX = 2^31-1.

@@ -251,7 +251,11 @@ bool validate_nodes(const DNode* nodes, size_t n_nodes, size_t n_tris, std::stri
         int nr = 0;
 #if PRT_BVH_WIDTH == 4
         for (int c = 0; c < 4; ++c)
-            if (nodes[i].ref[c] != (int32_t)0x80000000) refs[nr++] = nodes[i].ref[c];
+            if (nodes[i].ref[c] != (int32_t)0x80000000) {
+                if (c != nr) return bad("unused slot before a used one"); // the traversal only checks the refs of slots 2 and 3
+                refs[nr++] = nodes[i].ref[c];
+            }
+        if (n_tris == 1 && nr == 2 && refs[1] == refs[0]) nr = 1; // the one-triangle root lists its leaf twice
 #else
         refs[nr++] = nodes[i].ref0;
         if (!(n_tris == 1 && nodes[i].ref1 == nodes[i].ref0)) refs[nr++] = nodes[i].ref1;
@@ -259,6 +263,7 @@ bool validate_nodes(const DNode* nodes, size_t n_nodes, size_t n_tris, std::stri
         if (phase == 0) {
             if (++visited > n_nodes) return bad("cycle or shared node");
             if (nr < 1) return bad("node without children");
+            if (PRT_BVH_WIDTH == 4 && nr < 2 && n_tris != 1) return bad("wide node with fewer than two children");
             st.push_back({i, 1});
             for (int c = 0; c < nr; ++c) {
                 if (refs[c] >= 0) {
@@ -434,7 +439,6 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
         nodes.emplace_back();
         todo.push_back({0, 0, stack_budget, 0});
         uint32_t wide_depth = 0;
-        const bool single = n == 1; // the one-triangle root lists its leaf twice: keep one copy
         while (!todo.empty()) {
             const Open o = todo.back();
             todo.pop_back();
@@ -442,7 +446,8 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
             Kid kids[4];
             int nk = 0;
             kids[nk++] = kid_of(fn[o.bin], 0);
-            if (!single) kids[nk++] = kid_of(fn[o.bin], 1);
+            kids[nk++] = kid_of(fn[o.bin], 1); // every wide node has >= 2 children in slots 0, 1 (the traversal relies on it): the
+                                               // one-triangle root keeps both copies of its leaf, like the reference's span-1 node
             while (nk < 4) {
                 int best = -1;
                 float best_area = -1.f;

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -16,7 +17,7 @@
 #include "prt_host.h"
 
 namespace prt {
-int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth);
+int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth, bool pad);
 int render_permutation(int feat);
 int render_lds_budget(int feat, int stack_depth);
 size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds);
@@ -42,7 +43,7 @@ void launch_gather_tris(const DTri* tri_in, const DTriShade* shade_in, const uin
 // fp32 fast mode (prt_kernels_f32.hip): K1 and K3 on float records derived from the resident fp64 ones
 namespace prt32 {
 typedef DSceneT<float> Scene32;
-int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth);
+int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth, bool pad);
 int render_lds_budget(int feat, int stack_depth);
 size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds);
 void launch_trace(const Scene32& S, const PrtRay* d_rays, size_t n, PrtHit* d_hits, DCounters* d_ctr, bool count, int n_cu,
@@ -396,7 +397,18 @@ static int upload_impl(PrtScene* s, int device) {
         void* p = nullptr;
         PRT_HIP(hipMalloc(&p, std::max<size_t>(n * (size_t)stride, 256)));
         s->allocs.push_back(p);
-        if (n) PRT_HIP(hipMemcpy2D(p, stride, dt.data(), sizeof(DTri), sizeof(DTri), n, hipMemcpyHostToDevice));
+        if (n) {
+            // the padded array is laid out on the host and goes up in one copy (a 2-D copy of millions of 96-byte rows
+            // from pageable memory is served row by row)
+            std::vector<char> padded;
+            try {
+                padded.assign(n * (size_t)stride, 0);
+            } catch (const std::bad_alloc&) {
+                return fail(PRT_E_OOM, "prt_scene_upload: out of host memory for the padded triangle records");
+            }
+            for (size_t i = 0; i < n; ++i) std::memcpy(padded.data() + i * (size_t)stride, &dt[i], sizeof(DTri));
+            PRT_HIP(hipMemcpy(p, padded.data(), padded.size(), hipMemcpyHostToDevice));
+        }
         *out = static_cast<const DTri*>(p);
         return PRT_OK;
     };
@@ -474,11 +486,19 @@ static int upload_impl(PrtScene* s, int device) {
     d.light_area = s->lights.area;
     d.n_nodes = s->device_bvh ? (uint32_t)s->bvh_info.n_nodes : (uint32_t)s->bvh.nodes.size();
     d.n_tris = (uint32_t)n;
-    d.coord_scale = s->bvh.coord_scale;
+    d.slab_scale = s->bvh.coord_scale;
     for (int a = 0; a < 3; ++a) {
         d.grid_origin[a] = s->bvh.grid_origin[a];
         d.grid_step[a] = s->bvh.grid_step[a];
     }
+#if PRT_NODE16
+    {
+        // box coordinates reach the slab test relative to the grid origin: what bounds its rounding is the grid's extent
+        double e = 0.0;
+        for (int a = 0; a < 3; ++a) e = std::max(e, 65535.0 * (double)s->bvh.grid_step[a]);
+        d.slab_scale = std::nextafter((float)e, std::numeric_limits<float>::infinity());
+    }
+#endif
     for (PrtScene::CallSlot& q : s->slots) {
         PRT_HIP(hipMalloc(reinterpret_cast<void**>(&q.d_ctr), sizeof(DCounters)));
         PRT_HIP(hipMemset(q.d_ctr, 0, sizeof(DCounters)));
@@ -503,8 +523,9 @@ static int upload_impl(PrtScene* s, int device) {
                 &s->mat_lds, &s->ltri_lds, &s->light_lds);
     static_assert(sizeof(DLightNode) == 16 && sizeof(DLightTri) % 16 == 0, "LDS staging copies 16-byte pieces");
     const size_t tables = prt::render_table_bytes(s->light_lds, s->mat_lds, s->ltri_lds);
-    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat, tables, PRT_STACK_DEPTH);
-    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, tables, PRT_STACK_DEPTH);
+    const bool pad = d.tri_stride == PRT_TRI_PAD_STRIDE(double) && sizeof(DTri) != PRT_TRI_PAD_STRIDE(double);
+    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat, tables, PRT_STACK_DEPTH, pad);
+    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, tables, PRT_STACK_DEPTH, pad);
     return PRT_OK;
 }
 
@@ -625,7 +646,7 @@ static int ensure_f32_impl(PrtScene* s) {
     f.light_area = (float)d.light_area;
     f.n_nodes = d.n_nodes;
     f.n_tris = d.n_tris;
-    f.coord_scale = d.coord_scale;
+    f.slab_scale = d.slab_scale;
     for (int a = 0; a < 3; ++a) {
         f.grid_origin[a] = d.grid_origin[a];
         f.grid_step[a] = d.grid_step[a];
@@ -660,8 +681,9 @@ static int ensure_f32_impl(PrtScene* s) {
     size_tables(s, prt32::render_lds_budget(s->feat, s->stack_depth32), sizeof(DMaterialT<float>), sizeof(DLightTriT<float>),
                 sizeof(DLightNodeT<float>), &s->mat_lds32, &s->ltri_lds32, &s->light_lds32);
     const size_t tables = prt32::render_table_bytes(s->light_lds32, s->mat_lds32, s->ltri_lds32);
-    s->blocks_per_cu32[0] = prt32::render_blocks_per_cu(false, s->feat, tables, s->stack_depth32);
-    s->blocks_per_cu32[1] = prt32::render_blocks_per_cu(true, s->feat, tables, s->stack_depth32);
+    const bool pad = stride == PRT_TRI_PAD_STRIDE(float) && sizeof(DTriT<float>) != PRT_TRI_PAD_STRIDE(float);
+    s->blocks_per_cu32[0] = prt32::render_blocks_per_cu(false, s->feat, tables, s->stack_depth32, pad);
+    s->blocks_per_cu32[1] = prt32::render_blocks_per_cu(true, s->feat, tables, s->stack_depth32, pad);
     s->f32_ready = true;
     return PRT_OK;
 }
@@ -866,7 +888,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     if (const char* e = std::getenv("PRT_TUNE_INNER_MIN")) P.inner_min = std::atoi(e);
     if (const char* e = std::getenv("PRT_TUNE_SCRAMBLE")) P.scramble = std::atoi(e); // experiment: incoherent pixel order
     for (int c = 0; c < 3; ++c) P.background[c] = p->background[c];
-    P.seed = p->seed;
+    P.seed_key = prt::seed_key(p->seed); // the seed is hashed on its own, once per launch (prt_device.h, Rng)
     int tile = p->tile_size > 0 ? p->tile_size : 32;
     tile = std::max(8, (tile + 7) / 8 * 8);
     P.tile = tile;
@@ -972,7 +994,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
             P32.spp = P.spp; P32.max_depth = P.max_depth; P32.sample_lights = P.sample_lights; P32.chunks = P.chunks;
             P32.rr = (float)P.rr; P32.inv_rr = (float)P.inv_rr;
             conv_arr(P32.background, P.background, 3);
-            P32.seed = P.seed;
+            P32.seed_key = P.seed_key;
             P32.tile = P.tile; P32.tiles_x = P.tiles_x; P32.tiles_y = P.tiles_y; P32.n_tiles = P.n_tiles;
             P32.rank = P.rank; P32.nranks = P.nranks; P32.owned_tiles = P.owned_tiles; P32.jitter = P.jitter;
             P32.keep = P.keep; P32.leaf_batch = P.leaf_batch; P32.inner_min = P.inner_min; P32.scramble = P.scramble;

@@ -32,6 +32,12 @@ typedef real4_of<real>::type real4;
 #ifndef PRT_BOX_ROTATE
 #define PRT_BOX_ROTATE (PRT_BVH_WIDTH == 4) // 4-wide nodes: packed ranges rotated by the ray's direction sign instead of min/max per axis
 #endif
+#ifndef PRT_SLOT_CHECK
+#define PRT_SLOT_CHECK 1
+#endif
+#ifndef PRT_GRID_REL
+#define PRT_GRID_REL 1
+#endif
 #ifndef PRT_BOX_PK
 #define PRT_BOX_PK 1 // K3 permutations other than the lean one: the two plane parameters of an axis through one v_pk_fma_f32
 #endif
@@ -137,8 +143,10 @@ PRT_DEV d3 normalize_len(d3 v, real& len) {
 
 // ------------------------------------------------------------------ keyed counter RNG
 // Replaces the reference's global std::rand() (RandomNumberGenerator.h:16-19) by a stream keyed on
-// (seed, pixel, sample): the key is hashed (two splitmix64 finalisers) into the state of a xoroshiro64* generator;
-// each draw yields 31 bits so xi = r / 2^31 has rand()'s granularity.
+// (seed, pixel, sample): the seed is hashed on its own (once per launch, on the host: seed_key()), the result is combined
+// with (pixel, sample) and hashed again into the state of a xoroshiro64* generator; each draw yields 31 bits so
+// xi = r / 2^31 has rand()'s granularity.  Hashing the seed separately keeps the streams of different seeds unrelated:
+// folded linearly into one key, seed s+1 reused seed s's streams with neighbouring sample indices swapped.
 PRT_DEV uint64_t mix64(uint64_t z) {
     z ^= z >> 30;
     z *= 0xBF58476D1CE4E5B9ULL;
@@ -147,13 +155,15 @@ PRT_DEV uint64_t mix64(uint64_t z) {
     z ^= z >> 31;
     return z;
 }
+PRT_DEV uint64_t seed_key(uint64_t seed) { return mix64(seed + 0x9E3779B97F4A7C15ULL); } // prt_host.h has the host twin
 struct Rng {
     uint64_t s;
-    PRT_DEV void seed(uint64_t seed, uint64_t pixel, uint64_t sample) {
-        // one finaliser over the whole key (Stafford's mix13 avalanches every input bit): pixel and sample are below 2^32
-        s = mix64((seed + 0x9E3779B97F4A7C15ULL) ^ ((pixel + 1) << 32) ^ (sample + 1));
+    // `key` = seed_key(seed); pixel and sample are below 2^32 (Stafford's mix13 avalanches every input bit)
+    PRT_DEV void seed_keyed(uint64_t key, uint64_t pixel, uint64_t sample) {
+        s = mix64(((uint64_t)((uint32_t)(key >> 32) ^ (uint32_t)(pixel + 1)) << 32) | ((uint32_t)key ^ (uint32_t)(sample + 1)));
         if (s == 0) s = 0x9E3779B97F4A7C15ULL; // the all-zero state is the generator's fixed point
     }
+    PRT_DEV void seed(uint64_t seed, uint64_t pixel, uint64_t sample) { seed_keyed(seed_key(seed), pixel, sample); }
     // xoroshiro64* started from the hashed key, top 31 bits: one quarter-rate 32-bit multiply per number instead of the
     // two 64-bit multiplies (eight quarter-rate instructions) of a splitmix hash per number — with the kernels VALU-bound
     // the cheaper stream is worth +4 % (measured against a trivial LCG: +5 %).  Same stream in oracle/pt_oracle.cpp.
@@ -254,10 +264,13 @@ PRT_DEV float f32_down(real x) {
 
 // Per-ray constants of the fp32 slab test.  A box plane at coordinate b = g0 + q*gs (q = the node's
 // 16-bit grid index; gs = 1, g0 = 0 for fp32 nodes) is crossed at t(q) = fma(q, idq, c) with
-// idq = gs*id, id ~ 1/d (v_rcp_f32, 1 ulp), c = (g0 - o)*id.  The roundings of o, 1/d, gs*id, the
-// subtraction, the product and the fma sum to <= 9 * 2^-24 * (|o|+B) * |id| in t (B = largest box
-// coordinate); pad = 2^-20 * (|o|+B) * |id| covers them, subtracted on the entry plane and added on
-// the exit plane.  |id| is clamped to 1e28 so a zero direction component never yields inf - inf.
+// idq = gs*id, id ~ 1/d (v_rcp_f32, 1 ulp), c = r*id, r = g0 - o: the ray origin RELATIVE TO THE GRID ORIGIN, subtracted
+// in the precision the origin comes in and rounded to fp32 once — so the rounding of the test scales with the size of
+// the scene and the ray's distance from it, not with where the scene sits in the world (a unit scene at coordinate 1e6
+// is culled as well as one at the origin).  The roundings of r, 1/d, gs*id, the product and the fma sum to
+// <= 6 * 2^-24 * (|r| + E) * |id| in t (E = the grid's largest extent, or the largest |coordinate| for fp32 nodes);
+// pad = 2^-20 * (|r| + E) * |id| covers them, subtracted on the entry plane and added on the exit plane.  |id| is
+// clamped to 1e28 so a zero direction component never yields inf - inf.
 struct SlabAxis {
     float idq, c_lo, c_hi;
 #if PRT_BOX_ROTATE
@@ -265,14 +278,18 @@ struct SlabAxis {
                   // low half is always the ENTRY plane and c_lo / c_hi are the entry / exit constants
 #endif
 };
-PRT_DEV SlabAxis slab_axis(real o, real d, float B, float g0, float gs) {
+PRT_DEV SlabAxis slab_axis(real o, real d, float E, float g0, float gs) {
     SlabAxis a;
     const float df = (float)d;
     float id = __builtin_amdgcn_rcpf(df);
     if (!(fabsf(id) <= 1e28f)) id = copysignf(1e28f, df);
-    const float of = (float)o;
-    const float c = (g0 - of) * id;
-    const float pad = fabsf(id) * (fabsf(of) + B) * 9.5367432e-7f;
+#if PRT_GRID_REL
+    const float r = (float)((real)g0 - o);
+#else
+    const float r = g0 - (float)o;
+#endif
+    const float c = r * id;
+    const float pad = fmaf(E, fabsf(id), fabsf(c)) * 9.5367432e-7f; // (|r| + E) * |id| * 2^-20 with |c| = |r| |id|
     a.idq = gs * id;
 #if PRT_BOX_ROTATE
     a.c_lo = c - pad; // entry plane
@@ -318,13 +335,13 @@ struct Trav {
     PRT_DEV void start(const DScene& S, real tmin_, real tmax_) {
         tmin = tmin_;
 #if PRT_NODE16
-        ax = slab_axis(o.x, d.x, S.coord_scale, S.grid_origin[0], S.grid_step[0]);
-        ay = slab_axis(o.y, d.y, S.coord_scale, S.grid_origin[1], S.grid_step[1]);
-        az = slab_axis(o.z, d.z, S.coord_scale, S.grid_origin[2], S.grid_step[2]);
+        ax = slab_axis(o.x, d.x, S.slab_scale, S.grid_origin[0], S.grid_step[0]);
+        ay = slab_axis(o.y, d.y, S.slab_scale, S.grid_origin[1], S.grid_step[1]);
+        az = slab_axis(o.z, d.z, S.slab_scale, S.grid_origin[2], S.grid_step[2]);
 #else
-        ax = slab_axis(o.x, d.x, S.coord_scale, 0.f, 1.f);
-        ay = slab_axis(o.y, d.y, S.coord_scale, 0.f, 1.f);
-        az = slab_axis(o.z, d.z, S.coord_scale, 0.f, 1.f);
+        ax = slab_axis(o.x, d.x, S.slab_scale, 0.f, 1.f);
+        ay = slab_axis(o.y, d.y, S.slab_scale, 0.f, 1.f);
+        az = slab_axis(o.z, d.z, S.slab_scale, 0.f, 1.f);
 #endif
         tminf = f32_down(tmin_);
         tbestf = f32_up(tmax_);
@@ -341,7 +358,7 @@ struct Trav {
     PRT_DEV void box4(uint32_t x, uint32_t y, uint32_t z, float& n, float& f) const {
 #if PRT_BOX_ROTATE
         // no min/max per axis: after the rotation the low half IS the entry plane.  An unused slot (inverted range on
-        // every axis) comes out with entry beyond exit and can never be hit.
+        // every axis) comes out with entry beyond exit for every ray near the scene (see inner_step for the others).
         x = __builtin_amdgcn_alignbit(x, x, ax.rot);
         y = __builtin_amdgcn_alignbit(y, y, ay.rot);
         z = __builtin_amdgcn_alignbit(z, z, az.rot);
@@ -394,15 +411,30 @@ struct Trav {
         // entry distances are >= tminf; as unsigned integers positive floats order like the floats themselves
         // (a non-positive tmin only costs ordering quality, never correctness)
 #if PRT_BOX_ROTATE
+        // Both builders fill a node's slots from the front and every node has at least two children, so only slots 2
+        // and 3 can be unused (ref 0x80000000, inverted range).  The inverted range alone does not keep a ray out of
+        // them: the pad grows with the ray's distance from the scene, and from ~2^19 scene sizes away it exceeds the
+        // whole grid — entry <= exit then holds for the empty slot as well, and a traversal that descended into it
+        // would lose its stack or never end.  Hence the two explicit checks.
         uint32_t k0 = n0 <= f0 ? __float_as_uint(n0) : 0xffffffffu;
         uint32_t k1 = n1 <= f1 ? __float_as_uint(n1) : 0xffffffffu;
+#if PRT_SLOT_CHECK
+        uint32_t k2 = (n2 <= f2 && rf.z != 0x80000000u) ? __float_as_uint(n2) : 0xffffffffu;
+        uint32_t k3 = (n3 <= f3 && rf.w != 0x80000000u) ? __float_as_uint(n3) : 0xffffffffu;
+#else
         uint32_t k2 = n2 <= f2 ? __float_as_uint(n2) : 0xffffffffu;
         uint32_t k3 = n3 <= f3 ? __float_as_uint(n3) : 0xffffffffu;
+#endif
 #else
         uint32_t k0 = (n0 <= f0 && rf.x != 0x80000000u) ? __float_as_uint(n0) : 0xffffffffu;
         uint32_t k1 = (n1 <= f1 && rf.y != 0x80000000u) ? __float_as_uint(n1) : 0xffffffffu;
+#if PRT_SLOT_CHECK
         uint32_t k2 = (n2 <= f2 && rf.z != 0x80000000u) ? __float_as_uint(n2) : 0xffffffffu;
         uint32_t k3 = (n3 <= f3 && rf.w != 0x80000000u) ? __float_as_uint(n3) : 0xffffffffu;
+#else
+        uint32_t k2 = n2 <= f2 ? __float_as_uint(n2) : 0xffffffffu;
+        uint32_t k3 = n3 <= f3 ? __float_as_uint(n3) : 0xffffffffu;
+#endif
 #endif
         uint32_t r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
 #define PRT_CE(ka, ra, kb, rb)                  \

@@ -80,4 +80,15 @@ void build_light_tree(const PrtSceneDesc& d, const std::vector<HostTri>& tris, c
 // Camera::Initialize (Camera.cpp:75-106).
 void setup_camera(const PrtCamera& c, DCamera& out);
 
+// Host twin of the device's seed_key() (prt_device.h, Rng): the seed of a launch is hashed once, here.
+inline uint64_t seed_key(uint64_t seed) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ULL;
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return z;
+}
+
 } // namespace prt

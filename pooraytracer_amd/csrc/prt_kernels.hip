@@ -494,7 +494,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
             }
             if (state == ST_NEW_SAMPLE) {
                 // per-sample stream keyed (seed, j*W+i, s); Camera::GetRay (Camera.cpp:108-117): pixel centre, no jitter
-                rng.seed(P.seed, (uint64_t)py * (uint64_t)C.width + (uint64_t)px, (uint64_t)s);
+                rng.seed_keyed(P.seed_key, (uint64_t)py * (uint64_t)C.width + (uint64_t)px, (uint64_t)s);
                 real fx = (real)px, fy = (real)py;
                 if (P.jitter) { // the disabled SampleSquare() offset of Camera.cpp:110-111, drawn per sample: y first (g++ argument order)
                     fy += rng.next() - RL(0.5);
@@ -715,9 +715,11 @@ static RenderKernel render_kernel(bool count, int feat, bool llds, bool pad) {
 
 static size_t stack_bytes(int stack_depth) { return PRT_DYN_STACK ? (size_t)PRT_BLOCK * stack_depth * sizeof(uint32_t) : 0; }
 
-int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth) {
+// Resident blocks per CU of the instantiation a launch will use (`pad`: the scene's records sit at the padded stride —
+// a different function with its own register count).
+int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth, bool pad) {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel(count, feat, table_bytes != 0, false), PRT_BLOCK,
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel(count, feat, table_bytes != 0, pad), PRT_BLOCK,
                                                                 table_bytes + stack_bytes(stack_depth));
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;

@@ -51,7 +51,8 @@ typedef PRT_REAL prt_real;
 #if PRT_BVH_WIDTH == 4
 // 64 bytes = four 16-byte loads per node visit: the x ranges of the four children, their y ranges, their z ranges,
 // the four refs.  A range is lo | hi << 16 on the same 65536^3 grid as the 2-wide node.  Unused slots hold an
-// inverted range (lo = 0xffff, hi = 0) on every axis, which no ray can hit, and ref = 0x80000000.
+// inverted range (lo = 0xffff, hi = 0) on every axis and ref = 0x80000000; slots fill from the front and every node has
+// at least two children, so only slots 2 and 3 can be unused (the traversal checks their refs).
 struct alignas(64) DNode {
     uint32_t bx[4], by[4], bz[4];
     int32_t ref[4]; // >=0: inner node index; <0: leaf, ~ref = (first_tri << 3) | (count-1)
@@ -178,7 +179,8 @@ struct DSceneT {
     int32_t n_lights;
     R light_area;  // GetArea() of the top-level lights BVHNode
     uint32_t n_nodes, n_tris;
-    float coord_scale;  // largest |coordinate| of any BVH box (fp32, rounded up): bounds the slab-test rounding
+    float slab_scale;   // E of the slab test's pad (prt_device.h, slab_axis): PRT_NODE16 the largest extent of the quantisation
+                        // grid (box coordinates are taken relative to its origin); fp32 nodes: the largest |coordinate| of any box
     float pad_;
     float grid_origin[3]; // PRT_NODE16: box coordinate = grid_origin + q * grid_step
     float grid_step[3];
@@ -203,7 +205,7 @@ struct DRenderParamsT {
     int32_t spp, max_depth, sample_lights, chunks;
     R rr, inv_rr;
     R background[3];
-    uint64_t seed;
+    uint64_t seed_key; // mix64(seed + golden ratio), hashed on the host (Rng::seed_keyed)
     int32_t tile, tiles_x, tiles_y, n_tiles;
     int32_t rank, nranks, owned_tiles, jitter; // jitter: per-sample SampleSquare pixel offset (Camera.cpp:110-111)
     int32_t keep, leaf_batch, inner_min, scramble;

@@ -60,7 +60,9 @@ static int check_tree(const BuiltBVH& b, const std::vector<HostTri>& tris) {
                 if (nd.bx[i] != 0x0000ffffu || nd.by[i] != 0x0000ffffu || nd.bz[i] != 0x0000ffffu) return fail("unused slot is not inverted");
                 continue;
             }
+            if (i != kids) return fail("unused slot before a used one"); // the traversal checks the refs of slots 2 and 3 only
             ++kids;
+            if (n == 1 && i == 1 && nd.ref[1] == nd.ref[0]) continue; // the one-triangle root lists its leaf twice (like the reference's span-1 node)
             Box c;
             const uint32_t w[3] = {nd.bx[i], nd.by[i], nd.bz[i]};
             for (int a = 0; a < 3; ++a) {
@@ -71,7 +73,7 @@ static int check_tree(const BuiltBVH& b, const std::vector<HostTri>& tris) {
             }
             stack.push_back({nd.ref[i], c, it.depth + 1});
         }
-        if (kids < 2 && n > 1) return fail("wide node with fewer than two children");
+        if (kids < 2) return fail("wide node with fewer than two children");
         continue;
 #else
         Box c0, c1;

@@ -455,7 +455,8 @@ def test_lds_tables_and_plain_kernels_agree(gpu, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scale,offset", [(1e-4, (0.0, 0.0, 0.0)), (1.0, (4.0e4, -2.5e4, 1.0e4)), (3.0e3, (1.0e6, 2.0e6, -3.0e6))])
+@pytest.mark.parametrize("scale,offset", [(1e-4, (0.0, 0.0, 0.0)), (1.0, (4.0e4, -2.5e4, 1.0e4)), (3.0e3, (1.0e6, 2.0e6, -3.0e6)),
+                                          (0.5, (1.0e6, 1.0e6, 1.0e6)), (5.0, (6.0e6, -6.0e6, 6.0e6))])
 def test_scaled_and_translated_scene_hits(gpu, scale, offset):
     """The fp32 box tests work on a 16-bit grid over the scene bounds with a per-ray pad proportional to
     |origin| + scene extent: they must stay conservative when the scene is tiny, far from the origin, or large
@@ -488,6 +489,55 @@ def test_scaled_and_translated_scene_hits(gpu, scale, offset):
     check(sc.trace_closest(rays))
     # the device-built tree obeys the same bounds
     check(api.Scene(data, device_bvh=True).upload(gpu).trace_closest(rays))
+    # the box test works relative to the grid origin: where the scene sits in the world does not loosen the culling
+    # (with the pad proportional to the world coordinate a unit scene at 1e6 was not culled at all)
+    if scale < 0.1:  # (a 2e-4 wide scene is mostly the reference's 1e-4 minimum box padding, AABB.cpp:76-82: nothing to cull)
+        return
+    sc.trace_closest(rays[:20000], count_work=True)
+    far = sc.counters()["node_fetches"]
+    near = api.Scene(base).upload(gpu)
+    r0 = scenes.random_rays(20000, *base.bounds(), seed=31)
+    near.trace_closest(r0, count_work=True)
+    assert far <= 1.6 * near.counters()["node_fetches"], (far, near.counters()["node_fetches"])
+
+
+@pytest.mark.parametrize("dist", [3.0e6, 1.0e9])
+def test_far_ray_origins_end_and_hit_what_the_oracle_hits(gpu, dist):
+    """from ~2^19 scene sizes away the per-ray pad of the fp32 box test exceeds the whole quantisation grid,
+    so the inverted range of an unused child slot no longer rejects the ray; the traversal checks the slot's ref as
+    well (descending into the empty slot lost the stack or never ended).  Rays from far outside a unit scene, aimed at
+    it: every traversal ends and finds the oracle's triangle."""
+    data = scenes.cornell_box(ball_subdiv=2, width=16, height=16)
+    sc = api.Scene(data).upload(gpu)
+    orc = oracle.Oracle(data)
+    rng = np.random.default_rng(5)
+    n = 4096
+    lo, hi = data.bounds()
+    tgt = lo + rng.random((n, 3)) * (hi - lo)
+    u = rng.normal(size=(n, 3))
+    o = u / np.linalg.norm(u, axis=1, keepdims=True) * dist
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.zeros(n, dtype=_abi.RAY_DTYPE)
+    rays["o"], rays["d"], rays["tmin"], rays["tmax"] = o, d, 1e-4, np.inf
+    b = orc.trace_closest(rays)
+    for s in (sc, api.Scene(data, device_bvh=True).upload(gpu)):
+        g = s.trace_closest(rays)
+        assert np.array_equal(g["prim"] >= 0, b["prim"] >= 0)
+        hit = b["prim"] >= 0
+        assert hit.mean() > 0.5
+        # t = (D - n.o) / (n.d) cancels ~dist digits
+        assert np.all(np.abs(g["t"][hit] - b["t"][hit]) <= 1e-9 * dist * 1e-3 + 1e-12 * b["t"][hit])
+        assert (g["prim"][hit] != b["prim"][hit]).mean() < 2e-2  # at this distance neighbouring triangles tie within rounding
+    # K3 with the camera that far away (a telephoto view of the box): finishes, and the frame is the oracle's
+    import copy
+    cam = copy.copy(data.camera)
+    eye = np.asarray(cam.look_at, dtype=np.float64) + np.array([0.05, 0.03, 1.0]) / np.linalg.norm([0.05, 0.03, 1.0]) * dist
+    cam = scenes.Camera(16, 16, float(np.degrees(2 * np.arctan(1.2 / dist))), tuple(eye), tuple(cam.look_at))
+    img = sc.render(camera=cam, spp=4, max_depth=4, seed=3)
+    ref, _ = orc.render(camera=cam, spp=4, max_depth=4, seed=3)
+    assert np.isfinite(img).all() and img.mean() > 0
+    assert abs(img.mean() - ref.mean()) <= 0.05 * ref.mean()  # camera rays tie between neighbouring triangles at this distance
 
 
 def test_failed_upload_leaves_scene_unusable_but_sane(gpu, monkeypatch):

@@ -93,6 +93,27 @@ def test_rng_stream_properties():
     assert np.array_equal(a, oracle.rng_stream(1, 5, 7, 4096))
 
 
+def test_seeds_share_no_streams():
+    """The seed is hashed on its own before it meets (pixel, sample): no (sample) stream of one seed reappears under a
+    neighbouring seed (folded linearly into one key, seed 2 had reused seed 1's streams with sample indices swapped in
+    pairs — averaging frames of different seeds then reduced no variance)."""
+    first = {s: {oracle.rng_stream(s, 5, k, 1)[0] for k in range(512)} for s in (1, 2, 3, 1 << 32, (1 << 32) + 1)}
+    seeds = list(first)
+    for i, a in enumerate(seeds):
+        assert len(first[a]) >= 510  # 31-bit values: a chance repeat among 512 is possible, a systematic one is not
+        for b in seeds[i + 1:]:
+            assert len(first[a] & first[b]) <= 1, (a, b)
+    # and on the quantity that matters: per-sample radiance of one pixel under seed 1 and seed 2
+    sc = scenes.tiny_scene()
+    o = oracle.Oracle(sc)
+    px = [[sc.camera.width // 2, sc.camera.height // 2 + 5]]
+    r1 = o.render_samples(px, spp=256, max_depth=6, seed=1)[0]
+    r2 = o.render_samples(px, spp=256, max_depth=6, seed=2)[0]
+    lit1 = {tuple(v) for v in r1 if v.any()}
+    lit2 = {tuple(v) for v in r2 if v.any()}
+    assert len(lit1) > 100 and len(lit1 & lit2) == 0
+
+
 def test_camera_rays_pinhole():
     """Camera::Initialize/GetRay (Camera.cpp:75-117): pixel-centre rays, unnormalised, symmetric."""
     cam = scenes.Camera(8, 4, 90.0, (0, 0, 0), (0, 0, -1))
