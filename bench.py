@@ -66,7 +66,7 @@ RAY_WORKLOADS = {
     "s0-rays-cornell-coherent": ("cornell_box", {}, False),                 # ... and camera rays in pixel order (SURVEY §8d "coherent")
     "s4-rays-soup8m": ("triangle_soup", {"n_tris": 8_000_000}, True),       # HBM-resident; tree built on the GPU
 }
-EXTRA_AT_N1 = ["veach-mis", "bathroom2", "cornell-ct", "s0-rays-cornell", "s0-rays-cornell-coherent", "s4-rays-soup8m",
+EXTRA_AT_N1 = ["veach-mis", "bathroom2", "bathroom2-spp500", "cornell-ct", "s0-rays-cornell", "s0-rays-cornell-coherent", "s4-rays-soup8m",
                "cornell-box-f32", "veach-mis-f32", "bathroom2-f32"]
 TOL = 1e-9  # per channel, relative to max(1, |x|): fp64 on both sides, differences = FMA contraction + libm ulps
 
@@ -244,8 +244,10 @@ def cpu_baseline(scene_data, spp, depth, seed, target_s=8.0):
         "single_thread": {"value": round((c1["rays_closest"] + c1["rays_shadow"]) / dt1 / 1e6, 3), "unit": "Mrays/s",
                           "mpaths_per_s": round(c1["samples"] / dt1 / 1e6, 4),
                           "sample": f"row {mid} at spp={spp1} ({dt1:.2f} s)"},
-        "ray_count_note": "the oracle counts every world.Hit the reference issues; the GPU does not trace rays whose "
-                          "result the reference discards, so compare paths/s (gpu_over_cpu_paths), not rays/s",
+        "ray_count_note": "rays = BVH traversals actually executed.  The oracle counts every world.Hit the reference issues "
+                          "(one camera ray per SAMPLE); the GPU traces the pixel's one camera ray once per work item and starts "
+                          "every sample from that hit (Camera.cpp:53-57: the ray is the same for all samples), and does not trace "
+                          "rays whose result the reference discards — so compare paths/s (gpu_over_cpu_paths) and s/frame, not rays/s",
     }
     return out, img, (y0, y0 + rows)
 
@@ -570,7 +572,7 @@ def main():
                     if name in RAY_WORKLOADS:
                         extras.append(time_rays(ctx, name, 5, 1))
                     else:
-                        extras.append(time_render(ctx, name, 2 if name == "veach-mis" else 3, 1, cpu_target_s=3.0))
+                        extras.append(time_render(ctx, name, 2 if name in ("veach-mis", "bathroom2-spp500") else 3, 1, cpu_target_s=3.0))
         if rank == 0:
             rf = w["roofline"]
             out = {
@@ -602,12 +604,18 @@ def main():
                     out[k] = w[k]
             if config5 is not None:
                 out["config5"] = config5
-            if extras:
-                out["workloads"] = extras
             checks = [w] + extras + ([config5] if config5 else [])
             ok = all(x.get("parity_check", {}).get("ok", True) and x.get("assembled_equals_single_rank", True) and
                      x.get("f32", {}).get("parity_check", {}).get("ok", True) for x in checks)
             out["checks_ok"] = ok
+            # every workload's number in a few hundred bytes, ahead of the detailed entries (a truncated log still carries them)
+            out["workloads_summary"] = [
+                {"name": x["workload"], "mrays_per_s": x["value"], "ms_per_step": x["ms_per_step"], "mpaths_per_s": x.get("mpaths_per_s"),
+                 "bound": x["roofline"].get("bound"), "frac": x["roofline"].get("frac"),
+                 "parity_ok": x.get("parity_check", {}).get("ok"), "bad_px": x.get("parity_check", {}).get("bad_px")}
+                for x in checks]
+            if extras:
+                out["workloads"] = extras
             print(json.dumps(out), flush=True)
     if in_group:
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if rehearsal else "cuda")

@@ -14,6 +14,8 @@
  *                         (Source/HittableList.h:26-39 -> Source/BVH.cpp:51-61)
  *   prt_render            replaces Camera::Render(world, lights)      (Source/Camera.cpp:21-73)
  *   prt_render_device     same, framebuffer left in device memory for an RCCL reduce
+ *   prt_render_multi      same over several GPUs of this process: tiles + one RCCL reduce of the fp32 framebuffer
+ *                         (replaces the std::thread row bands of Source/Camera.cpp:46-71)
  *   prt_sample_lights     replaces lights.Sample(origin, record, pdf) (Source/HittableList.h:44-59,
  *                          Source/BVH.cpp:62-67,86-100, Source/Triangle.cpp:84-93) — test hook
  *   prt_get_counters      rays / node fetches / triangle tests / kernel ms of the last call
@@ -34,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 3
+#define PRT_ABI_VERSION 4
 
 /* error codes */
 #define PRT_OK 0
@@ -257,6 +259,40 @@ int prt_render(PrtScene* scene, const PrtCamera* cam, const PrtRenderParams* par
  * issue its calls from one host thread. */
 int prt_render_device(PrtScene* scene, const PrtCamera* cam, const PrtRenderParams* params,
                       void* d_rgb_f64, void* d_rgb_f32, int count_work, void* hip_stream);
+
+/*
+ * Camera::Render over several GPUs of one process — the reference's only parallel split is the thread fan-out over row
+ * bands inside Camera::Render (Source/Camera.cpp:46-71); here the frame is cut into 16x16 tiles dealt over the scenes:
+ * scenes[r] is the SAME scene description uploaded to a different device each (prt_scene_upload).  Every device renders
+ * its tiles into a zeroed full-size fp32 framebuffer, ONE RCCL reduce(sum, float) to scenes[0]'s device assembles the
+ * frame (disjoint tiles: x + 0 + ... + 0, the single-GPU fp32 image bit for bit) and one copy brings it to rgb_f32
+ * (W*H*3 floats).  n == 1 is prt_render's fp32 output.  All scenes on ONE device (tile-share replicas) are summed on
+ * that device without a collective; any other mix is refused.  If the RCCL communicator cannot be created the call
+ * fails (PRT_E_HIP): there is no host-side sum to fall back to.  Communicators are cached per device list.
+ */
+int prt_render_multi(PrtScene* const* scenes, int n, const PrtCamera* cam, const PrtRenderParams* params, float* rgb_f32);
+
+/*
+ * Test hook: RayColor of single camera samples through K3 itself (the production instantiation of k_render when `trace`
+ * is NULL, its counting instantiation otherwise) — what orc_render_samples is for the oracle.  Sample s of pixel
+ * (pixel_xy[2k], pixel_xy[2k+1]) draws from the stream keyed (params->seed, j*W+i, s) like in a frame, whatever params->spp
+ * says; radiance[k][s - sample_begin][3] is that sample's RayColor (not divided by spp).  params->precision must be
+ * PRT_PRECISION_F64; rank / tile / chunk fields are ignored.
+ * trace (optional) [n_pixels][sample_count][PRT_TRACE_WORDS]: the path's signature — word 0 = path vertices visited;
+ * then per vertex v (at most PRT_TRACE_VERTS): word 1+2v = triangle hit (PrtSceneDesc order, -1 = miss), word 2+2v = flags:
+ *   PRT_TRACE_NEE       the light sample passed n.wi > 0 and faces the shading point (Camera.cpp:153-154): a shadow ray was traced
+ *   PRT_TRACE_VISIBLE   ... and it reached the light: direct light was added (Camera.cpp:155-172)
+ *   PRT_TRACE_ROULETTE  RandomDouble() < russianRoulette (Camera.cpp:180)
+ *   PRT_TRACE_SCATTER   Material::Scatter returned true (Camera.cpp:182)
+ */
+#define PRT_TRACE_WORDS 64
+#define PRT_TRACE_VERTS 31
+#define PRT_TRACE_NEE 1
+#define PRT_TRACE_VISIBLE 2
+#define PRT_TRACE_ROULETTE 4
+#define PRT_TRACE_SCATTER 8
+int prt_render_samples(PrtScene* scene, const PrtCamera* cam, const PrtRenderParams* params, const int32_t* pixel_xy,
+                       size_t n_pixels, int32_t sample_begin, int32_t sample_count, double* radiance, int32_t* trace);
 
 int prt_get_counters(PrtScene* scene, PrtCounters* out);
 

@@ -84,6 +84,8 @@ def lib():
         L.orc_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p]
         L.orc_render_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_render_samples_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32,
+                                               C.c_void_p, C.c_void_p]
         L.orc_camera_rays.argtypes = [C.c_void_p, C.c_void_p]
         vp = C.c_void_p
         L.orc_material_eval.argtypes = [vp, C.c_int32, C.c_size_t, vp, vp, vp, C.c_uint64, vp]
@@ -197,13 +199,20 @@ class Oracle:
         counters = {f: getattr(cnt, f) for f, _ in OrcCounters._fields_}
         return rgb, counters
 
-    def render_samples(self, pixels_xy, camera=None, **kw):
+    def render_samples(self, pixels_xy, camera=None, sample_begin=0, sample_count=None, trace=False, **kw):
+        """RayColor per (pixel, sample): (n, count, 3); with trace=True also the path signatures (n, count, TRACE_WORDS)."""
         cam = camera or self.scene.camera
         c, p = _cam(cam), _params(**kw)
+        count = p.spp if sample_count is None else int(sample_count)
         px = np.ascontiguousarray(pixels_xy, dtype=np.int32).reshape(-1, 2)
-        out = np.zeros((px.shape[0], p.spp, 3), dtype=np.float64)
-        lib().orc_render_samples(self._h, C.byref(c), C.byref(p), px.ctypes.data, px.shape[0], out.ctypes.data)
-        return out
+        out = np.zeros((px.shape[0], count, 3), dtype=np.float64)
+        tr = np.zeros((px.shape[0], count, TRACE_WORDS), dtype=np.int32) if trace else None
+        lib().orc_render_samples_trace(self._h, C.byref(c), C.byref(p), px.ctypes.data, px.shape[0], int(sample_begin), count,
+                                       out.ctypes.data, tr.ctypes.data if trace else None)
+        return (out, tr) if trace else out
+
+
+TRACE_WORDS = 64
 
 
 def _f64(a, k):

@@ -138,6 +138,18 @@ void orc_render(const OrcScene*, const OrcCamera*, const OrcRenderParams*, doubl
 /* per-sample radiance of selected pixels: out[n_pixels][spp][3]. */
 void orc_render_samples(const OrcScene*, const OrcCamera*, const OrcRenderParams*,
                         const int32_t* pixel_xy, size_t n_pixels, double* out);
+/* Same for samples [sample_begin, sample_begin + sample_count) — out[n_pixels][sample_count][3] — and, when `trace` is not
+ * NULL, the signature of every path: trace[n_pixels][sample_count][ORC_TRACE_WORDS], word 0 = path vertices visited, then
+ * per vertex v (RayColor recursion level v): word 1+2v = triangle hit (description order, -1 = miss), word 2+2v = flags.
+ * Same layout and meaning as the product's prt_render_samples (include/prt.h). */
+#define ORC_TRACE_WORDS 64
+#define ORC_TRACE_VERTS 31
+#define ORC_TRACE_NEE 1       /* dot(n, wi) > 0 && light sample front-facing (Camera.cpp:153-154) */
+#define ORC_TRACE_VISIBLE 2   /* ... and visible: direct light added (Camera.cpp:155-172) */
+#define ORC_TRACE_ROULETTE 4  /* RandomDouble() < russianRoulette (Camera.cpp:180) */
+#define ORC_TRACE_SCATTER 8   /* Material::Scatter returned true (Camera.cpp:182) */
+void orc_render_samples_trace(const OrcScene*, const OrcCamera*, const OrcRenderParams*, const int32_t* pixel_xy,
+                              size_t n_pixels, int32_t sample_begin, int32_t sample_count, double* out, int32_t* trace);
 /* Material / texture hooks for the known-answer tests.  Directions are LOCAL (z = shading normal) for eval and the
  * CookTorrance terms, WORLD for scatter; item i uses the stream keyed (seed, i, 0).
  *   orc_material_eval      Material::Eval(wi, ctx{wo, uv})                              -> f[n][3]

@@ -800,6 +800,20 @@ struct Tracer {
     const Camera& cam;
     bool reusePeek;
     OrcCounters cnt{0, 0, 0, 0};
+    // Optional path signature of the sample being traced (oracle.h, ORC_TRACE_*): vertex v = maxDepth - depth.
+    int32_t* trace = nullptr;
+    bool mute = false; // below a continuation of zero throughput (the product does not trace those paths)
+    void TraceVertex(int depth, int prim) {
+        const int v = cam.maxDepth - depth;
+        if (!trace || mute || v >= ORC_TRACE_VERTS) return;
+        trace[0] = v + 1;
+        trace[1 + 2 * v] = prim;
+        trace[2 + 2 * v] = 0;
+    }
+    void TraceFlag(int depth, int bit) {
+        const int v = cam.maxDepth - depth;
+        if (trace && !mute && v < ORC_TRACE_VERTS) trace[2 + 2 * v] |= bit;
+    }
 
     // Camera::RayColor, Camera.cpp:119-204.  `pre` = the peek hit of the caller (same ray, same interval).
     V3 RayColor(const Ray& ray, int depth, const HitRecord* pre) {
@@ -813,7 +827,11 @@ struct Tracer {
             cnt.hit_calls++;
             hit = sc.WorldHit(ray, Interval(0.0001, kInf), record);
         }
-        if (!hit) return cam.background;
+        if (!hit) {
+            TraceVertex(depth, -1);
+            return cam.background;
+        }
+        TraceVertex(depth, record.prim);
         const Material& mat = sc.mats[record.material];
         if (mat.HasEmission()) return mat.GetEmission();
         const V3 ps = record.position;
@@ -835,7 +853,9 @@ struct Tracer {
             bool shadowHit = sc.WorldHit(shadowRay, Interval(0.001, std::numeric_limits<double>::max()), shadowRec);
             // departure B9: an escaping shadow ray counts as unoccluded
             bool visible = !shadowHit || (distance - length(ps - shadowRec.position) < 0.001);
+            if (dot(record.normal, lightDirection) > 0.0 && lrec.bFrontFace) TraceFlag(depth, ORC_TRACE_NEE);
             if (dot(record.normal, lightDirection) > 0.0 && lrec.bFrontFace && visible) {
+                TraceFlag(depth, ORC_TRACE_VISIBLE);
                 V3 emission = lightMaterial.GetEmission();
                 MaterialEvalContext context;
                 context.p = record.position;
@@ -855,7 +875,11 @@ struct Tracer {
         Ray scatteredRay{{0, 0, 0}, {0, 0, 0}};
         V3 attenuation{0, 0, 0};
         if (RandomDouble() < cam.russianRoulette) {
+            TraceFlag(depth, ORC_TRACE_ROULETTE);
             if (mat.Scatter(ray, record, attenuation, scatteredRay)) {
+                TraceFlag(depth, ORC_TRACE_SCATTER);
+                const bool wasMute = mute;
+                if (attenuation.x == 0. && attenuation.y == 0. && attenuation.z == 0.) mute = true;
                 if (cam.bSampleLights) {
                     HitRecord peek;
                     cnt.hit_calls++;
@@ -866,12 +890,17 @@ struct Tracer {
                             scatter = attenuation * RayColor(scatteredRay, depth - 1, pass) / cam.russianRoulette;
                         } else if (mat.SkipLightSampling()) {
                             scatter = attenuation * RayColor(scatteredRay, depth - 1, pass) / cam.russianRoulette;
+                        } else if (depth - 1 >= 0) {
+                            TraceVertex(depth - 1, peek.prim); // the vertex exists (a light reached by a bounce): it just adds nothing (Camera.cpp:191-195)
                         }
+                    } else if (depth - 1 >= 0) {
+                        TraceVertex(depth - 1, -1); // bounce miss: adds nothing (Camera.cpp:187)
                     }
                 } else {
                     if (depth - 1 >= 0) cnt.rays_closest++;
                     scatter = attenuation * RayColor(scatteredRay, depth - 1, nullptr) / cam.russianRoulette;
                 }
+                mute = wasMute;
             }
         }
         return direct + scatter;
@@ -1079,13 +1108,22 @@ void orc_render(const OrcScene* h, const OrcCamera* c, const OrcRenderParams* p,
 
 void orc_render_samples(const OrcScene* h, const OrcCamera* c, const OrcRenderParams* p, const int32_t* pixel_xy,
                         size_t n_pixels, double* out) {
+    orc_render_samples_trace(h, c, p, pixel_xy, n_pixels, 0, p->spp, out, nullptr);
+}
+
+void orc_render_samples_trace(const OrcScene* h, const OrcCamera* c, const OrcRenderParams* p, const int32_t* pixel_xy,
+                              size_t n_pixels, int32_t sample_begin, int32_t sample_count, double* out, int32_t* trace) {
     Camera cam = MakeCamera(c, p);
     Tracer tr{h->sc, cam, true};
     for (size_t k = 0; k < n_pixels; ++k) {
-        for (int s = 0; s < cam.samplesPerPixel; ++s) {
-            V3 r = tr.Sample(pixel_xy[k * 2], pixel_xy[k * 2 + 1], s, p->seed);
-            double* o = out + (k * cam.samplesPerPixel + s) * 3;
-            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+        for (int s = 0; s < sample_count; ++s) {
+            const size_t o = k * (size_t)sample_count + (size_t)s;
+            if (trace) {
+                tr.trace = trace + o * ORC_TRACE_WORDS;
+                std::memset(tr.trace, 0, ORC_TRACE_WORDS * sizeof(int32_t));
+            }
+            V3 r = tr.Sample(pixel_xy[k * 2], pixel_xy[k * 2 + 1], sample_begin + s, p->seed);
+            out[o * 3] = r.x; out[o * 3 + 1] = r.y; out[o * 3 + 2] = r.z;
         }
     }
 }

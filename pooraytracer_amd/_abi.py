@@ -5,7 +5,9 @@ tests/test_abi.py checks sizes and that every declared symbol is exported.
 """
 import ctypes as C
 
-PRT_ABI_VERSION = 3
+PRT_ABI_VERSION = 4
+TRACE_WORDS, TRACE_VERTS = 64, 31           # prt.h PRT_TRACE_*
+TRACE_NEE, TRACE_VISIBLE, TRACE_ROULETTE, TRACE_SCATTER = 1, 2, 4, 8
 PRECISION_F64, PRECISION_F32 = 0, 1
 
 PRT_OK = 0
@@ -175,6 +177,8 @@ assert LIGHT_SAMPLE_DTYPE.itemsize == C.sizeof(PrtLightSample) == 64
 # every symbol include/prt.h declares
 EXPORTS = [
     "prt_abi_version",
+    "prt_render_samples",
+    "prt_render_multi",
     "prt_last_error",
     "prt_device_count",
     "prt_scene_create",

@@ -64,6 +64,8 @@ def load():
     L.prt_material_eval.argtypes = [vp, i32, sz, vp, vp, vp, u64, vp]
     L.prt_material_scatter.argtypes = [vp, i32, sz, vp, vp, vp, vp, u64, vp, vp, vp]
     L.prt_texture_value.argtypes = [vp, i32, sz, vp, vp]
+    L.prt_render_samples.argtypes = [vp, vp, vp, vp, sz, i32, i32, vp, vp]
+    L.prt_render_multi.argtypes = [vp, i32, vp, vp, vp]
     if L.prt_abi_version() != _abi.PRT_ABI_VERSION:
         raise PrtError(-101, "ABI version mismatch between _abi.py and libprt_hip.so")
     _lib = L
@@ -187,6 +189,19 @@ class Scene:
                                  out32.ctypes.data if f32 else None))
         return (out64, out32) if f32 else out64
 
+    def render_samples(self, pixels_xy, camera=None, sample_begin=0, sample_count=None, trace=False, **kw):
+        """RayColor of single camera samples through K3 (test hook, include/prt.h): (n_pixels, count, 3) float64 and, with
+        trace=True, the paths' signatures (n_pixels, count, TRACE_WORDS) int32.  kw as for render(); spp = the default count."""
+        cam = camera or self.data.camera
+        c, p = _abi.make_camera(cam), _abi.make_params(**kw)
+        count = p.spp if sample_count is None else int(sample_count)
+        px = np.ascontiguousarray(pixels_xy, dtype=np.int32).reshape(-1, 2)
+        out = np.zeros((px.shape[0], count, 3), dtype=np.float64)
+        tr = np.zeros((px.shape[0], count, _abi.TRACE_WORDS), dtype=np.int32) if trace else None
+        _check(load().prt_render_samples(self._h, C.byref(c), C.byref(p), px.ctypes.data, px.shape[0], int(sample_begin), count,
+                                         out.ctypes.data, tr.ctypes.data if trace else None))
+        return (out, tr) if trace else out
+
     def render_device(self, d_f64_ptr, d_f32_ptr, camera=None, count_work=False, stream=None, **kw):
         """Asynchronous render into device buffers (raw device pointers, e.g. torch tensor.data_ptr())."""
         cam = camera or self.data.camera
@@ -200,3 +215,14 @@ class Scene:
         c = _abi.PrtCounters()
         _check(load().prt_get_counters(self._h, C.byref(c)))
         return {f: getattr(c, f) for f, _ in _abi.PrtCounters._fields_}
+
+
+def render_multi(scene_list, camera=None, **kw):
+    """prt_render_multi: one frame over several uploaded replicas of a scene (different GPUs: tiles + one RCCL reduce of the
+    fp32 framebuffer; one GPU: tile shares summed on it).  Returns (H, W, 3) float32."""
+    cam = camera or scene_list[0].data.camera
+    c, p = _abi.make_camera(cam), _abi.make_params(**kw)
+    hs = (C.c_void_p * len(scene_list))(*[s._h for s in scene_list])
+    out = np.zeros((cam.height, cam.width, 3), dtype=np.float32)
+    _check(load().prt_render_multi(hs, len(scene_list), C.byref(c), C.byref(p), out.ctypes.data))
+    return out

@@ -26,7 +26,7 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     if out is None and not force and not stale():
         return LIB
     out = out or LIB
-    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", out] + [os.path.join(CSRC, f) for f in SOURCES]
+    cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-o", out] + [os.path.join(CSRC, f) for f in SOURCES] + ["-lrccl"]  # RCCL: prt_render_multi's reduce
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

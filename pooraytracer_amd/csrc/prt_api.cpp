@@ -2,14 +2,18 @@
 // preparation on create, SoA upload, kernel launches, counters.  There is no CPU compute path:
 // every compute entry point needs a HIP device and fails with PRT_E_NO_DEVICE / PRT_E_HIP otherwise.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -30,6 +34,7 @@ void launch_finalize(const DCamera& C, const DRenderParams& P, const double* d_p
 void launch_sample_lights(const DScene& S, const double* d_origins, size_t n, uint64_t seed, PrtLightSample* d_out,
                           hipStream_t st);
 void launch_tonemap(const float* d_in, size_t n, uint8_t* d_out, hipStream_t st);
+void launch_add_f32(float* dst, const float* src, size_t n, hipStream_t st);
 void launch_material_eval(const DScene& S, int material, const double* wi, const double* wo, const double* uv, size_t n,
                           uint64_t seed, double* out, hipStream_t st);
 void launch_material_scatter(const DScene& S, int material, const double* rd, const double* normal, const double* tangent,
@@ -111,6 +116,7 @@ struct PrtScene {
         hipEvent_t done = nullptr; // recorded behind the last kernel of the call that used this slot
         bool timed = false;
         bool counted = false;
+        uint64_t samples = 0; // camera samples of the call (render: owned pixels inside the image x spp; the kernel does not count them)
     };
     CallSlot slots[2];
     int cur = 0; // slot of the most recent call (prt_get_counters reads it)
@@ -124,6 +130,8 @@ struct PrtScene {
         return &q;
     }
     PrtCounters last{};
+    float* multi_fb = nullptr; // prt_render_multi: this device's full-size fp32 framebuffer (kept between frames)
+    size_t multi_fb_cap = 0;
 
     int fail_upload_at = -1, n_uploads = 0; // test hook (PRT_TEST_FAIL_UPLOAD=k): the k-th table upload reports out-of-memory
     template <typename T>
@@ -141,6 +149,9 @@ struct PrtScene {
         if (device >= 0) (void)hipSetDevice(device);
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
+        if (multi_fb) (void)hipFree(multi_fb);
+        multi_fb = nullptr;
+        multi_fb_cap = 0;
         for (CallSlot& q : slots) {
             if (q.d_ctr) (void)hipFree(q.d_ctr);
             if (q.d_partial) (void)hipFree(q.d_partial);
@@ -723,6 +734,7 @@ int prt_trace_closest_device_prec(PrtScene* s, const void* d_rays, size_t n, voi
     PRT_HIP(hipEventRecord(q.done, st));
     q.timed = true;
     q.counted = count_work != 0;
+    q.samples = 0;
     return PRT_OK;
 }
 
@@ -1016,6 +1028,15 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     PRT_HIP(hipEventRecord(q.done, st));
     q.timed = true;
     q.counted = count;
+    q.samples = 0;
+    if (P.n_items) { // pixels of this rank's tiles that lie inside the image, times spp
+        uint64_t px = 0;
+        for (int k = P.rank; k < P.n_tiles; k += P.nranks) {
+            const int ty = k / P.tiles_x, kx = k - ty * P.tiles_x, tx = (kx + 3 * ty) % P.tiles_x; // prt_device.h, owned_to_pixel
+            px += (uint64_t)std::max(0, std::min(tile, C.width - tx * tile)) * (uint64_t)std::max(0, std::min(tile, C.height - ty * tile));
+        }
+        q.samples = px * (uint64_t)spp;
+    }
     return PRT_OK;
 }
 
@@ -1047,6 +1068,194 @@ int prt_render(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* p, doub
     return rc;
 }
 
+// Test hook (prt.h): single camera samples through K3.  One work item per (listed pixel, sample): the sample chunks of a
+// launch are the samples themselves (at most PRT_MAX_CHUNKS per launch), spp = 1 so that nothing is scaled, and the item's
+// partial sum IS the sample's RayColor.
+int prt_render_samples(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* p, const int32_t* pixel_xy, size_t n_pixels,
+                       int32_t sample_begin, int32_t sample_count, double* radiance, int32_t* trace) {
+    int rc = require_uploaded(s, "prt_render_samples");
+    if (rc) return rc;
+    if (!cam || !p || (n_pixels && (!pixel_xy || !radiance))) return fail(PRT_E_INVALID, "prt_render_samples: null argument");
+    if (cam->width < 1 || cam->height < 1) return fail(PRT_E_INVALID, "prt_render_samples: bad image size");
+    if (p->precision != PRT_PRECISION_F64) return fail(PRT_E_INVALID, "prt_render_samples: fp64 only");
+    if (sample_begin < 0 || sample_count < 0) return fail(PRT_E_INVALID, "prt_render_samples: bad sample range");
+    if (n_pixels == 0 || sample_count == 0) return PRT_OK;
+    if (n_pixels * (size_t)PRT_MAX_CHUNKS >= 0xffffffffULL) return fail(PRT_E_LIMIT, "prt_render_samples: too many pixels");
+    std::vector<int32_t> pix(n_pixels);
+    for (size_t k = 0; k < n_pixels; ++k) {
+        const int32_t i = pixel_xy[2 * k], j = pixel_xy[2 * k + 1];
+        if (i < 0 || j < 0 || i >= cam->width || j >= cam->height) return fail(PRT_E_INVALID, "prt_render_samples: pixel outside the image");
+        pix[k] = j * cam->width + i;
+    }
+    DCamera C;
+    prt::setup_camera(*cam, C);
+    DRenderParams P;
+    std::memset(&P, 0, sizeof(P));
+    P.spp = 1;
+    P.max_depth = p->max_depth;
+    P.sample_lights = p->sample_lights ? 1 : 0;
+    P.rr = p->russian_roulette;
+    P.inv_rr = 1.0 / p->russian_roulette;
+    P.keep = s->feat == 0 ? 28 : 20;
+    P.leaf_batch = s->feat == 0 ? 48 : 40;
+    P.inner_min = s->feat == 0 ? 20 : 12;
+    P.scramble = PRT_ITEMS_FROM_LIST;
+    for (int c = 0; c < 3; ++c) P.background[c] = p->background[c];
+    P.seed_key = prt::seed_key(p->seed);
+    P.tile = 8;
+    P.tiles_x = P.tiles_y = P.n_tiles = 1;
+    P.rank = 0;
+    P.nranks = 1;
+    P.owned_tiles = 1;
+    P.jitter = p->pixel_jitter ? 1 : 0;
+    P.light_lds = s->light_lds;
+    P.mat_lds = s->mat_lds;
+    P.ltri_lds = s->ltri_lds;
+    P.stack_depth = PRT_STACK_DEPTH;
+    P.items_per_chunk = n_pixels;
+    const bool count = trace != nullptr;
+    const int bpc = s->blocks_per_cu[count ? 1 : 0];
+    int32_t *d_pix = nullptr, *d_trace = nullptr;
+    double* d_part = nullptr;
+    const size_t per_launch = n_pixels * (size_t)std::min<int>(sample_count, PRT_MAX_CHUNKS);
+    PRT_HIP(hipMalloc(reinterpret_cast<void**>(&d_pix), n_pixels * sizeof(int32_t)));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_part), per_launch * 3 * sizeof(double));
+    if (e == hipSuccess && trace) e = hipMalloc(reinterpret_cast<void**>(&d_trace), per_launch * PRT_TRACE_WORDS * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpy(d_pix, pix.data(), n_pixels * sizeof(int32_t), hipMemcpyHostToDevice);
+    std::vector<double> part(per_launch * 3);
+    std::vector<int32_t> tr(trace ? per_launch * PRT_TRACE_WORDS : 0);
+    hipError_t we = hipSuccess;
+    for (int32_t s0 = 0; e == hipSuccess && s0 < sample_count; s0 += PRT_MAX_CHUNKS) {
+        const int chunks = std::min<int>(PRT_MAX_CHUNKS, sample_count - s0);
+        for (int c = 0; c <= chunks; ++c) P.chunk_begin[c] = sample_begin + s0 + c;
+        P.chunks = chunks;
+        P.n_items = P.items_per_chunk * (uint64_t)chunks;
+        PrtScene::CallSlot& q = *s->next_slot(nullptr, &we);
+        if ((e = we) != hipSuccess) break;
+        if ((e = hipMemsetAsync(q.d_ctr, 0, sizeof(DCounters), nullptr)) != hipSuccess) break;
+        const void* ptrs[2] = {d_pix, d_trace};
+        if ((e = hipMemcpy(reinterpret_cast<char*>(q.d_ctr) + offsetof(DCounters, pixel_list), ptrs, sizeof(ptrs), hipMemcpyHostToDevice)) != hipSuccess) break;
+        if (d_trace && (e = hipMemset(d_trace, 0, (size_t)P.n_items * PRT_TRACE_WORDS * sizeof(int32_t))) != hipSuccess) break;
+        (void)hipEventRecord(q.ev0, nullptr);
+        const uint64_t want = (P.n_items + PRT_BLOCK - 1) / PRT_BLOCK;
+        const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)s->n_cu * bpc));
+        if (P.max_depth >= 0) prt::launch_render(s->d, C, P, d_part, q.d_ctr, count, s->feat, grid, nullptr);
+        else if ((e = hipMemset(d_part, 0, (size_t)P.n_items * 3 * sizeof(double))) != hipSuccess) break;
+        if ((e = hipGetLastError()) != hipSuccess) break;
+        (void)hipEventRecord(q.ev1, nullptr);
+        (void)hipEventRecord(q.done, nullptr);
+        q.timed = true;
+        q.counted = count;
+        q.samples = P.max_depth >= 0 ? P.n_items : 0;
+        if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+        if ((e = hipMemcpy(part.data(), d_part, (size_t)P.n_items * 3 * sizeof(double), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if (trace && (e = hipMemcpy(tr.data(), d_trace, (size_t)P.n_items * PRT_TRACE_WORDS * sizeof(int32_t), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        for (int c = 0; c < chunks; ++c)
+            for (size_t k = 0; k < n_pixels; ++k) { // item = chunk * n_pixels + k  ->  out[k][s0 + c]
+                const size_t item = (size_t)c * n_pixels + k, o = k * (size_t)sample_count + (size_t)(s0 + c);
+                std::memcpy(radiance + o * 3, part.data() + item * 3, 3 * sizeof(double));
+                if (trace) std::memcpy(trace + o * PRT_TRACE_WORDS, tr.data() + item * PRT_TRACE_WORDS, PRT_TRACE_WORDS * sizeof(int32_t));
+            }
+    }
+    (void)hipFree(d_pix);
+    if (d_part) (void)hipFree(d_part);
+    if (d_trace) (void)hipFree(d_trace);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? PRT_E_OOM : PRT_E_HIP, std::string("prt_render_samples: ") + hipGetErrorString(e));
+    return PRT_OK;
+}
+
+namespace {
+// One RCCL communicator set per list of devices, created on first use and kept for the life of the process
+// (ncclCommInitAll takes hundreds of milliseconds; a frame takes tens).
+struct CommSet {
+    std::vector<ncclComm_t> comms;
+};
+std::mutex g_comm_mutex;
+std::map<std::vector<int>, CommSet> g_comms;
+} // namespace
+
+// Camera::Render over several GPUs of this process (prt.h).  Single host thread: every device's launches are
+// asynchronous; the reduce is one grouped RCCL call.
+int prt_render_multi(PrtScene* const* scenes, int n, const PrtCamera* cam, const PrtRenderParams* p, float* rgb_f32) {
+    if (!scenes || n < 1 || !cam || !p || !rgb_f32) return fail(PRT_E_INVALID, "prt_render_multi: null argument");
+    if (cam->width < 1 || cam->height < 1) return fail(PRT_E_INVALID, "prt_render_multi: bad image size");
+    std::vector<int> devs(n);
+    for (int r = 0; r < n; ++r) {
+        if (!scenes[r]) return fail(PRT_E_INVALID, "prt_render_multi: null scene");
+        if (scenes[r]->device < 0) return fail(PRT_E_NO_DEVICE, "prt_render_multi: a scene is not uploaded to a HIP device (no CPU path exists)");
+        for (int q = 0; q < r; ++q)
+            if (scenes[q] == scenes[r]) return fail(PRT_E_INVALID, "prt_render_multi: the same scene handle twice (one handle per tile share)");
+        devs[r] = scenes[r]->device;
+    }
+    bool all_same = true, all_distinct = true;
+    for (int r = 0; r < n; ++r)
+        for (int q = 0; q < r; ++q) {
+            if (devs[q] == devs[r]) all_distinct = false;
+            else all_same = false;
+        }
+    if (n > 1 && !all_same && !all_distinct)
+        return fail(PRT_E_INVALID, "prt_render_multi: scenes must sit on pairwise different devices (RCCL reduce) or all on one device");
+    const size_t npx = (size_t)cam->width * cam->height * 3;
+    // every share renders its tiles into its device's zeroed full-size fp32 framebuffer
+    for (int r = 0; r < n; ++r) {
+        PrtScene* s = scenes[r];
+        PRT_HIP(hipSetDevice(s->device));
+        if (s->multi_fb_cap < npx) {
+            if (s->multi_fb) (void)hipFree(s->multi_fb);
+            s->multi_fb = nullptr;
+            s->multi_fb_cap = 0;
+            PRT_HIP(hipMalloc(reinterpret_cast<void**>(&s->multi_fb), npx * sizeof(float)));
+            s->multi_fb_cap = npx;
+        }
+        PrtRenderParams pr = *p;
+        pr.tile_size = n > 1 ? 16 : p->tile_size;
+        pr.rank = r;
+        pr.nranks = n;
+        const int rc = prt_render_device(s, cam, &pr, nullptr, s->multi_fb, 0, nullptr);
+        if (rc != PRT_OK) return rc;
+    }
+    if (n > 1 && all_same) {
+        // tile shares of one device (replicas; a rehearsal of the multi-GPU path on one GPU): summed where they are
+        PRT_HIP(hipSetDevice(devs[0]));
+        for (int r = 1; r < n; ++r) prt::launch_add_f32(scenes[0]->multi_fb, scenes[r]->multi_fb, npx, nullptr);
+        PRT_HIP(hipGetLastError());
+    } else if (n > 1) {
+        // ONE collective: reduce(sum) of the fp32 framebuffers to the first device over RCCL (xGMI between the GPUs of a
+        // node).  Tiles are disjoint, so every element is x + 0 + ... + 0: the result is the single-GPU image bit for bit.
+        CommSet* cs = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_comm_mutex);
+            auto it = g_comms.find(devs);
+            if (it == g_comms.end()) {
+                CommSet fresh;
+                fresh.comms.resize(n);
+                const ncclResult_t nr = ncclCommInitAll(fresh.comms.data(), n, devs.data());
+                if (nr != ncclSuccess)
+                    return fail(PRT_E_HIP, std::string("prt_render_multi: ncclCommInitAll failed: ") + ncclGetErrorString(nr) +
+                                               " (no host-side fallback exists: the frame is not assembled)");
+                it = g_comms.emplace(devs, std::move(fresh)).first;
+            }
+            cs = &it->second;
+        }
+        ncclResult_t nr = ncclGroupStart();
+        for (int r = 0; r < n && nr == ncclSuccess; ++r) {
+            PRT_HIP(hipSetDevice(devs[r]));
+            nr = ncclReduce(scenes[r]->multi_fb, scenes[r]->multi_fb, npx, ncclFloat, ncclSum, 0, cs->comms[r], nullptr);
+        }
+        const ncclResult_t ne = ncclGroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess) return fail(PRT_E_HIP, std::string("prt_render_multi: ncclReduce failed: ") + ncclGetErrorString(nr));
+        for (int r = 1; r < n; ++r) { // the root's copy below only waits for the root's stream
+            PRT_HIP(hipSetDevice(devs[r]));
+            PRT_HIP(hipDeviceSynchronize());
+        }
+    }
+    PRT_HIP(hipSetDevice(devs[0]));
+    PRT_HIP(hipDeviceSynchronize());
+    PRT_HIP(hipMemcpy(rgb_f32, scenes[0]->multi_fb, npx * sizeof(float), hipMemcpyDeviceToHost));
+    return PRT_OK;
+}
+
 int prt_get_counters(PrtScene* s, PrtCounters* out) {
     if (!s || !out) return fail(PRT_E_INVALID, "prt_get_counters: null argument");
     PrtCounters c = s->last;
@@ -1064,7 +1273,7 @@ int prt_get_counters(PrtScene* s, PrtCounters* out) {
         c.rays_shadow = h.rays_shadow;
         c.node_fetches = h.node_fetches;
         c.tri_tests = h.tri_tests;
-        c.samples = h.samples;
+        c.samples = q.samples;
         c.inner_rounds = h.inner_rounds;
         c.leaf_rounds = h.leaf_rounds;
         c.refills = h.refills;

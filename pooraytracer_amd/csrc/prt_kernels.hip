@@ -200,7 +200,11 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
 }
 
 // ------------------------------------------------------------------------------------------- K3
-enum : int { ST_FETCH = 0, ST_NEW_SAMPLE = 1, ST_CLOSEST = 2, ST_SHADOW = 3, ST_DONE = 4 };
+enum : int { ST_FETCH = 0, ST_NEW_SAMPLE = 1, ST_CLOSEST = 2, ST_SHADOW = 3, ST_DONE = 4, ST_PRIMARY = 5 };
+// The camera ray of a pixel is the same for every sample (Camera.cpp:53-57: GetRay once per pixel, no jitter): K3 traces
+// it ONCE per work item (ST_PRIMARY) and parks its hit — t, barycentrics, triangle — in LDS, lane-strided; every sample of
+// the item starts from that hit instead of re-tracing the identical ray.  PRT_PH_WORDS dwords per lane.
+#define PRT_PH_WORDS ((int)(3 * sizeof(real) / 4 + 1))
 
 // Shading context of a hit, rebuilt from (incoming ray, HitInfo): HitRecord of Triangle::Hit
 // (Triangle.cpp:76-80,111) — position = ray(t), face-forwarded normal, tangent, uv.
@@ -234,6 +238,8 @@ template <bool COUNT, int FEAT, bool LLDS, bool PAD>
 __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     DScene S, DCamera C, DRenderParams P, double* __restrict__ partial, DCounters* ctr) {
     __shared__ uint32_t s_qoff[PRT_BLOCK / 64];
+    __shared__ unsigned long long s_rays[PRT_BLOCK / 64];
+    __shared__ uint32_t s_ph[(FEAT & PRT_FEAT_TEX) ? PRT_PH_WORDS : PRT_PH_WORDS - (int)(2 * sizeof(real) / 4)][PRT_BLOCK]; // the work item's primary hit (see ST_PRIMARY), read once per sample
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Dynamic LDS, sized by the host: the four waves' traversal stacks (P.stack_depth entries per lane, lane-strided),
     // then the shading tables.  The depth is a launch parameter because it decides how many blocks a CU holds: a tree
@@ -251,6 +257,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
 #endif
     if (lane == 0) {
         s_qoff[wave] = 0;
+        s_rays[wave] = 0ULL;
     }
     // light tree in LDS (see sample_lights)
     const DLightNode* lds_lights = reinterpret_cast<const DLightNode*>(s_dyn);
@@ -282,9 +289,33 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
 // pixelSamplesScale (Camera.cpp:56) with RayColor unrolled into sum_k beta_k * x_k; each term is scaled and
 // added on the spot, so no per-sample radiance has to live in registers across traversals.
 #define ADD_RADIANCE(x) PST_ST(S_ACC, PST_LD(S_ACC) + (PST_LD(S_BETA) * (x)) * inv_spp)
+// prt_render_samples with a trace buffer (counting instantiation, one sample per work item): the path's signature,
+// vertex v = max_depth - depth (prt.h, PRT_TRACE_*)
+#define TRACING (COUNT && P.scramble == PRT_ITEMS_FROM_LIST && ctr->trace != nullptr)
+#define TRACE_VERTEX(prim_)                                                     \
+    do {                                                                        \
+        if (TRACING) {                                                          \
+            const int v_ = P.max_depth - depth;                                 \
+            if (v_ < PRT_TRACE_VERTS) {                                         \
+                int32_t* tw_ = ctr->trace + (size_t)item * PRT_TRACE_WORDS;     \
+                tw_[0] = v_ + 1;                                                \
+                tw_[1 + 2 * v_] = (prim_);                                      \
+                tw_[2 + 2 * v_] = 0;                                            \
+            }                                                                   \
+        }                                                                       \
+    } while (0)
+#define TRACE_FLAG(bit_)                                                        \
+    do {                                                                        \
+        if (TRACING) {                                                          \
+            const int v_ = P.max_depth - depth;                                 \
+            if (v_ < PRT_TRACE_VERTS) ctr->trace[(size_t)item * PRT_TRACE_WORDS + 2 + 2 * v_] |= (bit_); \
+        }                                                                       \
+    } while (0)
 
     WorkCount wc{0, 0, 0, 0, 0};
-    uint32_t n_closest = 0, n_shadow = 0, n_samples = 0, n_refills = 0;
+    // Rays are counted per WAVE in LDS (ballot + popcount, one 64-bit LDS add by lane 0 per pass: closest | shadow << 32): no
+    // register holds a count.  Camera samples are not counted at all: their number follows from the launch (host).
+    uint32_t n_refills = 0;
 #if PRT_K3_TIMING
     // developer diagnostic (COUNT instantiation only): 100 MHz timestamps of this wave's start, of the first
     // failed item fetch and of its end are folded into inner_rounds / leaf_rounds / refills / tri_tests
@@ -319,6 +350,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     for (;;) {
         if (COUNT) n_refills++;
         PROF_MARK(0); // traversal rounds (and loop control) since the last mark
+        int started = 0; // this pass started a traversal of this kind on this lane (1 closest, 2 shadow): counted below, where the wave has reconverged
         if (!tr.active) {
             // ---------------- a traversal has just finished on this lane: consume its result
             bool end_sample = false, do_scatter = false;
@@ -328,13 +360,74 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
             // been consumed tr.o IS the shading point.
             bool have_fr = false;
             d3 fr_seen = mk3(0, 0, 0);
-            if (state == ST_CLOSEST) {
+            bool fresh = false; // a camera ray set up in this pass that has yet to be traced (pixel jitter only)
+            if (state == ST_PRIMARY) {
+                // the item's camera ray has been traced: its hit serves every sample of the item
+                // (the barycentrics are only ever read for texture coordinates: untextured permutations keep t and the triangle)
+                uint32_t* ph = &s_ph[0][threadIdx.x];
+                if (PRT_F32) {
+                    ph[0] = __float_as_uint((float)tr.hit.t);
+                    ph[PRT_BLOCK] = (uint32_t)tr.hit.tri;
+                    if (FEAT & PRT_FEAT_TEX) {
+                        ph[2 * PRT_BLOCK] = __float_as_uint((float)tr.hit.alpha);
+                        ph[3 * PRT_BLOCK] = __float_as_uint((float)tr.hit.beta);
+                    }
+                } else {
+                    const unsigned long long a = (unsigned long long)__double_as_longlong((double)tr.hit.t);
+                    ph[0] = (uint32_t)a; ph[PRT_BLOCK] = (uint32_t)(a >> 32);
+                    ph[2 * PRT_BLOCK] = (uint32_t)tr.hit.tri;
+                    if (FEAT & PRT_FEAT_TEX) {
+                        const unsigned long long b = (unsigned long long)__double_as_longlong((double)tr.hit.alpha), c = (unsigned long long)__double_as_longlong((double)tr.hit.beta);
+                        ph[3 * PRT_BLOCK] = (uint32_t)b; ph[4 * PRT_BLOCK] = (uint32_t)(b >> 32);
+                        ph[5 * PRT_BLOCK] = (uint32_t)c; ph[6 * PRT_BLOCK] = (uint32_t)(c >> 32);
+                    }
+                }
+                state = ST_NEW_SAMPLE;
+            }
+            if (state == ST_NEW_SAMPLE) {
+                // per-sample stream keyed (seed, j*W+i, s); Camera::GetRay (Camera.cpp:108-117): pixel centre, no jitter
+                rng.seed_keyed(P.seed_key, (uint64_t)py * (uint64_t)C.width + (uint64_t)px, (uint64_t)s);
+                real fx = (real)px, fy = (real)py;
+                if (P.jitter) { // the disabled SampleSquare() offset of Camera.cpp:110-111, drawn per sample: y first (g++ argument order)
+                    fy += rng.next() - RL(0.5);
+                    fx += rng.next() - RL(0.5);
+                    fresh = true; // its own camera ray per sample: traced below, consumed by a later pass
+                } else {
+                    const uint32_t* ph = &s_ph[0][threadIdx.x];
+                    if (PRT_F32) {
+                        tr.hit.t = (real)__uint_as_float(ph[0]);
+                        tr.hit.tri = (int32_t)ph[PRT_BLOCK];
+                        if (FEAT & PRT_FEAT_TEX) {
+                            tr.hit.alpha = (real)__uint_as_float(ph[2 * PRT_BLOCK]);
+                            tr.hit.beta = (real)__uint_as_float(ph[3 * PRT_BLOCK]);
+                        }
+                    } else {
+                        tr.hit.t = (real)__longlong_as_double((long long)(((unsigned long long)ph[PRT_BLOCK] << 32) | ph[0]));
+                        tr.hit.tri = (int32_t)ph[2 * PRT_BLOCK];
+                        if (FEAT & PRT_FEAT_TEX) {
+                            tr.hit.alpha = (real)__longlong_as_double((long long)(((unsigned long long)ph[4 * PRT_BLOCK] << 32) | ph[3 * PRT_BLOCK]));
+                            tr.hit.beta = (real)__longlong_as_double((long long)(((unsigned long long)ph[6 * PRT_BLOCK] << 32) | ph[5 * PRT_BLOCK]));
+                        }
+                    }
+                }
+                const d3 ps = ld3(C.pixel00) + fx * ld3(C.du) + fy * ld3(C.dv);
+                tr.o = ld3(C.center);
+                tr.d = ps - tr.o;
+                PST_ST(S_BETA, mk3(1, 1, 1));
+                depth = P.max_depth;
+                first = true;
+                prev_skip = false;
+                state = ST_CLOSEST;
+            }
+            if (state == ST_CLOSEST && !fresh) {
                 if (tr.hit.tri < 0) {
                     // miss: background for the camera ray (Camera.cpp:127); with bSampleLights a bounce miss adds 0 (:187)
                     if (first || !P.sample_lights) ADD_RADIANCE(ld3(P.background));
+                    TRACE_VERTEX(-1);
                     end_sample = true;
                 } else {
                     const DMaterial& m = MATERIAL(S.shade[tr.hit.tri].material);
+                    TRACE_VERTEX(S.shade[tr.hit.tri].prim);
                     if (m.has_emission) {
                         // Camera.cpp:129-132; via a bounce only after SkipLightSampling materials (:191-195)
                         if (first || !P.sample_lights || prev_skip) ADD_RADIANCE(ld3(m.emission));
@@ -355,6 +448,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                                 ltri = lp.tri;
                                 ldist = dist;
                                 tr.d = ldir;
+                                TRACE_FLAG(PRT_TRACE_NEE);
                                 state = ST_SHADOW; // trace the shadow ray, then scatter
                                 do_scatter = false;
                             }
@@ -400,6 +494,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     // Camera.cpp:172: emission*fr*cosT*cosTB/dist^2/pdf, the scalar factor folded into one division
                     const d3 direct = (emission * fr) * fast_div(cosT * cosTB, (dist * dist) * pdf);
                     ADD_RADIANCE(direct);
+                    TRACE_FLAG(PRT_TRACE_VISIBLE);
                 }
                 state = ST_CLOSEST;
                 do_scatter = true;
@@ -413,7 +508,9 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     const ShadeCtx c = make_ctx<FEAT, PAD>(S, rd, tr.hit.alpha, tr.hit.beta, sh_tri);
                     const DMaterial& m = MATERIAL(c.material);
                     d3 att, wi;
+                    TRACE_FLAG(PRT_TRACE_ROULETTE);
                     if (mat_scatter<FEAT>(S, m, rd, c.f, c.uv, rng, att, wi, have_fr, fr_seen)) {
+                        TRACE_FLAG(PRT_TRACE_SCATTER);
                         depth--; // RayColor(scattered, depth-1): returns 0 when depth-1 < 0
                         if (depth >= 0) {
                             const d3 beta = (PST_LD(S_BETA) * att) * P.inv_rr;
@@ -480,39 +577,38 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                     const uint32_t ipc = (uint32_t)P.items_per_chunk;
                     const uint32_t chunk = item / ipc;
                     const uint32_t oi = item - chunk * ipc;
-                    if (owned_to_pixel(P, C, oi, px, py)) {
+                    bool valid;
+                    if (P.scramble == PRT_ITEMS_FROM_LIST) { // prt_render_samples: the pixels of a list
+                        const int32_t pix = ctr->pixel_list[oi];
+                        py = pix / C.width;
+                        px = pix - py * C.width;
+                        valid = true;
+                        if (COUNT && ctr->trace != nullptr) ctr->trace[(size_t)item * PRT_TRACE_WORDS] = 0;
+                    } else {
+                        valid = owned_to_pixel(P, C, oi, px, py);
+                    }
+                    if (valid) {
                         s = P.chunk_begin[chunk];
                         s_end = P.chunk_begin[chunk + 1];
                         PST_ST(S_ACC, mk3(0, 0, 0));
-                        if (s < s_end) state = ST_NEW_SAMPLE;
-                        else {
+                        if (s >= s_end) {
                             double* o = partial + (size_t)item * 3;
                             o[0] = o[1] = o[2] = 0.0;
+                        } else if (P.jitter) {
+                            state = ST_NEW_SAMPLE; // a camera ray of its own per sample: set up at the top of the next pass
+                        } else {
+                            // Camera::GetRay (Camera.cpp:108-117), once per work item: the pixel's one camera ray
+                            const d3 ps = ld3(C.pixel00) + (real)px * ld3(C.du) + (real)py * ld3(C.dv);
+                            tr.o = ld3(C.center);
+                            tr.d = ps - tr.o;
+                            state = ST_PRIMARY;
                         }
                     }
                 }
             }
-            if (state == ST_NEW_SAMPLE) {
-                // per-sample stream keyed (seed, j*W+i, s); Camera::GetRay (Camera.cpp:108-117): pixel centre, no jitter
-                rng.seed_keyed(P.seed_key, (uint64_t)py * (uint64_t)C.width + (uint64_t)px, (uint64_t)s);
-                real fx = (real)px, fy = (real)py;
-                if (P.jitter) { // the disabled SampleSquare() offset of Camera.cpp:110-111, drawn per sample: y first (g++ argument order)
-                    fy += rng.next() - RL(0.5);
-                    fx += rng.next() - RL(0.5);
-                }
-                const d3 ps = ld3(C.pixel00) + fx * ld3(C.du) + fy * ld3(C.dv);
-                tr.o = ld3(C.center);
-                tr.d = ps - tr.o;
-                PST_ST(S_BETA, mk3(1, 1, 1));
-                depth = P.max_depth;
-                first = true;
-                prev_skip = false;
-                n_samples++;
-                state = ST_CLOSEST;
-            }
             PROF_MARK(3); // end of sample, item fetch, new sample
             // ---------------- start the traversal this lane needs next
-            if (state == ST_CLOSEST || state == ST_SHADOW) {
+            if (state == ST_CLOSEST || state == ST_SHADOW || state == ST_PRIMARY) {
                 // ONE traversal set-up for both kinds of ray (as two divergent call sites every pass executed both, one
                 // after the other: -1...2 %, 8 more spilled registers).  Camera / continuation rays: Interval(0.0001, inf),
                 // closest hit (Camera.cpp:125).  Shadow rays: Ray(ps, normalize(pl-ps)) (Camera.cpp:143-150); the reference
@@ -520,12 +616,15 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 // than dist - 0.001, so only [0.001, dist - 0.001] needs tracing and ANY hit in it settles the question:
                 // boxes beyond the light are culled from the start and traversal stops at the first accepted triangle.
                 const bool sh_ray = state == ST_SHADOW;
-                n_closest += sh_ray ? 0u : 1u;
-                n_shadow += sh_ray ? 1u : 0u;
+                started = sh_ray ? 2 : 1;
                 tr.start(S, sh_ray ? RL(0.001) : RL(0.0001), sh_ray ? ldist - RL(0.001) : PRT_INF);
             }
         }
         PROF_MARK(4); // traversal set-up
+        {
+            const unsigned long long nc = (unsigned long long)__popcll(__ballot(started == 1)), ns = (unsigned long long)__popcll(__ballot(started == 2));
+            if (lane == 0) atomicAdd(&s_rays[wave], nc | (ns << 32));
+        }
         if (__ballot(state != ST_DONE) == 0ULL) break;
 
         // ---------------- traversal steps until enough lanes have finished to be worth refilling
@@ -535,16 +634,13 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
         } while (wave_count(tr.active) > P.keep);
     }
 
-    unsigned long long a = wave_sum((unsigned long long)n_closest);
-    unsigned long long b = wave_sum((unsigned long long)n_shadow);
-    unsigned long long c = wave_sum((unsigned long long)n_samples);
     unsigned long long d = wave_sum((unsigned long long)wc.nodes);
     unsigned long long e = wave_sum((unsigned long long)wc.tris);
     unsigned long long f = wave_sum((unsigned long long)wc.tris_full);
     if (lane == 0) {
-        atomicAdd(&ctr->rays_closest, a);
-        atomicAdd(&ctr->rays_shadow, b);
-        atomicAdd(&ctr->samples, c);
+        const unsigned long long rays = s_rays[wave];
+        atomicAdd(&ctr->rays_closest, rays & 0xffffffffULL);
+        atomicAdd(&ctr->rays_shadow, rays >> 32);
         if (COUNT) {
             atomicAdd(&ctr->node_fetches, d);
             atomicAdd(&ctr->tri_full, f);
@@ -667,6 +763,12 @@ __global__ void k_tonemap(const float* __restrict__ in, size_t n, uint8_t* __res
     out[i] = (uint8_t)(sv * 255);
 }
 
+// dst += src (fp32 framebuffers of tile shares that live on ONE device: disjoint tiles, so every element is x + 0)
+__global__ void k_add_f32(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 #endif // !PRT_F32_TU
 
 } // namespace
@@ -686,7 +788,7 @@ int render_permutation(int feat) {
 int render_lds_budget(int feat, int stack_depth) {
     int blocks = render_waves(render_permutation(feat));
     if (PRT_F32_TU && stack_depth <= 32) blocks = PRT_F32_WAVES > 4 && stack_depth <= 24 ? 5 : 4; // fp32: registers allow a fourth wave per SIMD when the stacks do
-    return ((160 * 1024 / blocks - (int)sizeof(uint32_t) * stack_depth * PRT_BLOCK - 128) / 512) * 512;
+    return ((160 * 1024 / blocks - (int)sizeof(uint32_t) * (stack_depth + PRT_PH_WORDS) * PRT_BLOCK - 128) / 512) * 512; // stacks + parked primary hits
 }
 size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds) {
     return (size_t)light_lds * sizeof(DLightNode) + (size_t)mat_lds * sizeof(DMaterial) + (size_t)ltri_lds * sizeof(DLightTri);
@@ -821,6 +923,10 @@ void launch_material_scatter(const DScene& S, int material, const double* rd, co
 void launch_texture_value(const DScene& S, int texture, const double* uv, size_t n, double* out, hipStream_t st) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_texture_value, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S, texture, uv, n, out);
+}
+
+void launch_add_f32(float* dst, const float* src, size_t n, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_add_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dst, src, n);
 }
 
 void launch_tonemap(const float* d_in, size_t n, uint8_t* d_out, hipStream_t st) {

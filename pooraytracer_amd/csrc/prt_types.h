@@ -226,6 +226,7 @@ typedef DRenderParamsT<prt_real> DRenderParams;
 #define PRT_ITEM_QUEUES 16
 #endif
 #define PRT_QUEUE_STRIDE 32 // in 8-byte words: one counter per 256 bytes (different memory channels)
+#define PRT_ITEMS_FROM_LIST 2 // DRenderParams::scramble: pixels come from DCounters::pixel_list (prt_render_samples)
 
 // device-side counters, zeroed before each call
 struct DCounters {
@@ -233,6 +234,10 @@ struct DCounters {
     unsigned long long rays_closest, rays_shadow, node_fetches, tri_tests, samples;
     unsigned long long inner_rounds, leaf_rounds, refills; // COUNT builds: wave-level scheduling statistics
     unsigned long long tri_full; // COUNT builds: triangle tests that fetched the whole 128-byte record
-    unsigned long long pad_[PRT_QUEUE_STRIDE - 10];
+    // prt_render_samples (test hook, DRenderParams::scramble == PRT_ITEMS_FROM_LIST): work item oi renders pixel pixel_list[oi]
+    // (index j*W+i); the counting instantiation also writes each item's path signature to trace[item * PRT_TRACE_WORDS]
+    const int32_t* pixel_list;
+    int32_t* trace;
+    unsigned long long pad_[PRT_QUEUE_STRIDE - 12];
     unsigned long long queue[PRT_ITEM_QUEUES * PRT_QUEUE_STRIDE]; // queue[q * PRT_QUEUE_STRIDE] = next 64-item-block-local index of queue q
 };

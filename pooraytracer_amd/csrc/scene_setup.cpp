@@ -232,11 +232,16 @@ int32_t flatten_light(const RefBuilder& rb, const Obj& o, LightTree& out, const 
         return ~(int32_t)(out.tris.size() - 1);
     }
     const TNode& n = rb.nodes[o.node];
-    if (n.single) return flatten_light(rb, n.left, out, tris); // both branches reach the same child
+    // A span-1 node (left == right, BVH.cpp:21-23) over a TRIANGLE: either branch samples that triangle.  Over a NODE
+    // (the top-level node of a lights list with one mesh, main.cpp:45) the two branches differ: TraverseSample goes right
+    // when the float p is not below the child's area — sqrt(xi) * area rounds UP to the whole area for xi > 1 - 2^-24 —
+    // and descends the same child with p - area = 0, i.e. wraps around to the FIRST triangle of the CDF (BVH.cpp:93-98).
+    // The node is kept, with both refs on the one flattened child.
+    if (n.single && n.left.node < 0) return flatten_light(rb, n.left, out, tris);
     const int32_t idx = (int32_t)out.nodes.size();
     out.nodes.push_back(DLightNode{rb.area(n.left), 0, 0});
     const int32_t l = flatten_light(rb, n.left, out, tris);
-    const int32_t r = flatten_light(rb, n.right, out, tris);
+    const int32_t r = n.single ? l : flatten_light(rb, n.right, out, tris);
     out.nodes[idx].left = l;
     out.nodes[idx].right = r;
     return idx;
@@ -276,7 +281,7 @@ void build_light_tree(const PrtSceneDesc& d, const std::vector<HostTri>& tris, c
         for (size_t q = 0; q < order.size(); ++q) {
             const DLightNode& n = out.nodes[order[q]];
             if (n.left >= 0) order.push_back(n.left);
-            if (n.right >= 0) order.push_back(n.right);
+            if (n.right >= 0 && n.right != n.left) order.push_back(n.right); // (a span-1 node lists its child twice)
         }
         for (size_t i = 0; i < order.size(); ++i) newidx[order[i]] = (int32_t)i;
         std::vector<DLightNode> renum(order.size());

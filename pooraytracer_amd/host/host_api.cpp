@@ -385,28 +385,18 @@ void Camera::Render(Hittable& world, Hittable& lights) {
     if (devs.size() == 1) {
         check(prt_render(dc.scene, &c, &p, rgb.data(), nullptr), "prt_render");
     } else {
-        // One host thread per GPU, 16x16 tiles dealt over the devices exactly as bench.py deals them over
-        // ranks; every device leaves the other devices' tiles at 0, so adding the buffers is exact and the
-        // image equals the single-GPU one bit for bit (the per-sample RNG is keyed on the global pixel).
-        const int n = (int)devs.size();
-        std::vector<std::vector<double>> part(n - 1, std::vector<double>(rgb.size()));
-        std::vector<std::string> errors(n);
-        std::vector<std::thread> workers;
-        for (int r = 0; r < n; ++r)
-            workers.emplace_back([&, r] {
-                PrtRenderParams pr = p;
-                pr.tile_size = 16;
-                pr.rank = r;
-                pr.nranks = n;
-                PrtScene* sc = r == 0 ? dc.scene : dc.replicas[r - 1].scene;
-                double* out = r == 0 ? rgb.data() : part[r - 1].data();
-                if (prt_render(sc, &c, &pr, out, nullptr) != PRT_OK) errors[r] = prt_last_error();
-            });
-        for (auto& w : workers) w.join();
-        for (int r = 0; r < n; ++r)
-            if (!errors[r].empty()) throw std::runtime_error("prt_render (device " + std::to_string(devs[r]) + "): " + errors[r]);
-        for (const auto& pbuf : part)
-            for (size_t i = 0; i < rgb.size(); ++i) rgb[i] += pbuf[i];
+        // The reference's parallel split is Camera::Render's thread fan-out over row bands (Camera.cpp:46-71); here 16x16
+        // tiles are dealt over the devices exactly as bench.py deals them over ranks, every device renders its tiles into
+        // a zeroed fp32 framebuffer, and prt_render_multi assembles the frame with ONE RCCL reduce(sum) to the first
+        // device (disjoint tiles: x + 0 + ... + 0) and one copy to the host.  The multi-GPU frame is therefore the fp32
+        // framebuffer (what travels over xGMI); the per-sample RNG is keyed on the global pixel, so it equals the
+        // single-GPU image rounded to float bit for bit.  No host-side sum exists: a failing reduce fails the render.
+        std::vector<PrtScene*> scs;
+        scs.push_back(dc.scene);
+        for (size_t r = 1; r < devs.size(); ++r) scs.push_back(dc.replicas[r - 1].scene);
+        std::vector<float> rgb32(rgb.size());
+        check(prt_render_multi(scs.data(), (int)scs.size(), &c, &p, rgb32.data()), "prt_render_multi");
+        for (size_t i = 0; i < rgb.size(); ++i) rgb[i] = (double)rgb32[i];
     }
     colorAttachment.assign((size_t)imageWidth * imageHeight, color(0., 0., 0.)); // cleared every frame
     for (size_t i = 0; i < colorAttachment.size(); ++i) colorAttachment[i] = color(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);

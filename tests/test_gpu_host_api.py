@@ -40,8 +40,9 @@ def test_render_scene_driver_matches_binding_and_oracle(gpu, tmp_path):
 
 
 def test_camera_devices_and_device_bvh(gpu, tmp_path):
-    """Camera::devices cuts the frame into tiles over several scene replicas (here all on the one GPU of the
-    box, one host thread each) and sums the buffers: the image must equal the single-device one bit for bit.
+    """Camera::devices cuts the frame into tiles over several scene replicas (here all on the one GPU of the box: tile
+    shares summed on that device; on different GPUs the same call reduces over RCCL) through prt_render_multi, whose
+    frame is the fp32 framebuffer: it must equal the single-device image rounded to float, bit for bit.
     Camera::bBuildBvhOnDevice (GPU-built BVH) must not change the image either."""
     exe = build.build_host_example()
     data = scenes.mixed_materials(56, 40)
@@ -55,8 +56,35 @@ def test_camera_devices_and_device_bvh(gpu, tmp_path):
                            env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr + r.stdout
         outs[tag] = np.fromfile(out, dtype=np.float64)
-    assert np.array_equal(outs["one"], outs["three"])
+    assert np.array_equal(outs["one"].astype(np.float32).astype(np.float64), outs["three"])
     assert np.array_equal(outs["one"], outs["gpubvh"])
+
+
+def test_render_multi_on_one_device_and_over_rccl(gpu):
+    """prt_render_multi (the C-ABI entry Camera::devices goes through).  Replicas on ONE device: tile shares summed there.
+    Replicas on DIFFERENT devices (when the box has them): one ncclReduce(sum, float) to the first device.  Either way the
+    frame equals prt_render's fp32 output bit for bit (disjoint tiles: x + 0 + ... + 0).  Mixed placements, a handle
+    listed twice and scenes that are not uploaded are refused."""
+    data = scenes.mixed_materials(72, 56)
+    base = api.Scene(data).upload(gpu)
+    _, want = base.render(spp=6, max_depth=6, seed=3, f32=True)
+    reps = [api.Scene(data).upload(gpu) for _ in range(3)]
+    got = api.render_multi(reps, spp=6, max_depth=6, seed=3)
+    assert np.array_equal(got, want)
+    assert np.array_equal(api.render_multi(reps[:1], spp=6, max_depth=6, seed=3), want)
+    with pytest.raises(api.PrtError):
+        api.render_multi([reps[0], reps[0]], spp=2, max_depth=2)
+    with pytest.raises(api.PrtError):
+        api.render_multi([reps[0], api.Scene(data)], spp=2, max_depth=2)
+    ndev = api.device_count()
+    if ndev >= 2:
+        n = min(ndev, 4)
+        spread = [api.Scene(data).upload(d) for d in range(n)]
+        for _ in range(2):  # the second frame reuses the cached communicators
+            assert np.array_equal(api.render_multi(spread, spp=6, max_depth=6, seed=3), want)
+        if n >= 3:
+            with pytest.raises(api.PrtError):  # two on device 0, one on device 1: neither all-distinct nor all-same
+                api.render_multi([spread[0], reps[0], spread[1]], spp=2, max_depth=2)
 
 
 def test_camera_xml_override(gpu, tmp_path):
