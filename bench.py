@@ -261,7 +261,7 @@ def parity_rows(gpu_f64, ref_img, rows):
     bad = (rel > TOL).any(-1)
     return {"rows": [int(y0), int(y1)], "pixels": int(bad.size), "bad_px": int(bad.sum()),
             "max_rel": float(rel.max()) if rel.size else 0.0, "tolerance": TOL,
-            "ok": bool(bad.mean() <= 1e-3 if bad.size else True)}
+            "ok": bool(bad.mean() <= 2e-5 if bad.size else True)}  # observed: no pixel beyond the tolerance on any workload
 
 
 # ------------------------------------------------------------------------------------------------ workloads

@@ -104,6 +104,11 @@ struct PrtScene {
     int blocks_per_cu32[2] = {0, 0};
     int ltri_lds32 = 0, light_lds32 = 0, mat_lds32 = 0; // table sizes of the fp32 kernels (their own LDS budget)
     int stack_depth32 = PRT_STACK_DEPTH;                // LDS stack entries per lane of the fp32 render kernels
+    int stack_need = PRT_STACK_DEPTH;                   // stack entries a traversal of the resident tree can need at most
+    int stack_depth = PRT_STACK_DEPTH;                  // ... and what the fp64 render kernels get: that, rounded up to a multiple of 4
+    const DNode* d_nodes_shallow = nullptr;             // the same binary tree collapsed for PRT_STACK_SHALLOW entries (host build, deep trees), or null
+    uint32_t n_nodes_shallow = 0;
+    DScene d_k3{};                                      // the scene as K3 sees it: `d`, on the shallow tree when that buys LDS the kernel needs
     std::vector<void*> allocs;
     // Per-call device state, double-buffered: consecutive calls alternate slots, so a caller that
     // alternates two streams (and two framebuffers) can have frame k+1 filling the GPU while the last
@@ -530,13 +535,42 @@ static int upload_impl(PrtScene* s, int device) {
     // value per byte: the material table (must fit, <= 8 KB), all light triangles if there are at most 32, then
     // as many top levels of the light tree (breadth-first numbering) as the remaining budget holds.
     // Measured: materials cornell +2.5 %, bathroom2 +3 %, veach-mis +2 %; light tree veach-mis +5 %.
-    size_tables(s, prt::render_lds_budget(s->feat, PRT_STACK_DEPTH), sizeof(DMaterial), sizeof(DLightTri), sizeof(DLightNode),
+    // LDS traversal stacks of K3 are sized from what THIS tree can need (tree_stack_need), not from the builders' bound
+    {
+        int need = PRT_STACK_DEPTH;
+        if (!s->bvh_info.built_on_device) need = s->bvh.stack_need;
+        else if (d.n_nodes <= (1u << 21)) { // device-built: the nodes come back once for the count (at most 128 MB; larger trees keep the bound)
+            std::vector<DNode> hn(d.n_nodes);
+            PRT_HIP(hipMemcpy(hn.data(), d.nodes, (size_t)d.n_nodes * sizeof(DNode), hipMemcpyDeviceToHost));
+            need = prt::tree_stack_need(hn.data(), hn.size());
+        }
+        s->stack_need = std::min(std::max(need, 1), PRT_STACK_DEPTH);
+        s->d_k3 = d;
+        s->d_nodes_shallow = nullptr;
+        s->n_nodes_shallow = 0;
+        const int full_depth = PRT_STACK_DEPTH; // the fp64 render kernels keep static stacks of the builders' bound (a run-time depth cost them 1.2 %)
+        const bool tables_fit = prt::render_lds_budget(s->feat, full_depth) >= (int)(s->mats.size() * sizeof(DMaterial));
+        if (!tables_fit && s->stack_need > PRT_STACK_SHALLOW && !s->bvh_info.built_on_device && !s->bvh.nodes_shallow.empty()) {
+            // A deep tree whose stacks would leave a block no LDS for its shading tables at the kernel's occupancy: the host
+            // builder kept the same binary tree collapsed for 32 entries (same leaves, same triangle order, ~0.1 % more
+            // nodes, +2 % frame time on bathroom2).  K3 traverses that one then — losing a resident block costs far more
+            // (measured: 71.9 ms vs 47.8 ms per bathroom2 frame at two blocks per CU).  K1 keeps the wider tree.
+            if ((rc = s->up(s->bvh.nodes_shallow, &s->d_nodes_shallow))) return rc;
+            s->n_nodes_shallow = (uint32_t)s->bvh.nodes_shallow.size();
+            s->d_k3.nodes = s->d_nodes_shallow;
+            s->d_k3.n_nodes = s->n_nodes_shallow;
+            s->stack_need = std::min(s->stack_need, PRT_STACK_SHALLOW);
+        }
+        s->stack_depth = s->d_nodes_shallow ? PRT_STACK_SHALLOW : PRT_STACK_DEPTH;
+        if (std::getenv("PRT_TUNE_VERBOSE")) std::fprintf(stderr, "[prt] tree needs %d stack entries\n", s->stack_need);
+    }
+    size_tables(s, prt::render_lds_budget(s->feat, s->stack_depth), sizeof(DMaterial), sizeof(DLightTri), sizeof(DLightNode),
                 &s->mat_lds, &s->ltri_lds, &s->light_lds);
     static_assert(sizeof(DLightNode) == 16 && sizeof(DLightTri) % 16 == 0, "LDS staging copies 16-byte pieces");
     const size_t tables = prt::render_table_bytes(s->light_lds, s->mat_lds, s->ltri_lds);
     const bool pad = d.tri_stride == PRT_TRI_PAD_STRIDE(double) && sizeof(DTri) != PRT_TRI_PAD_STRIDE(double);
-    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat, tables, PRT_STACK_DEPTH, pad);
-    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, tables, PRT_STACK_DEPTH, pad);
+    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat, tables, s->stack_depth, pad);
+    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, tables, s->stack_depth, pad);
     return PRT_OK;
 }
 
@@ -667,23 +701,10 @@ static int ensure_f32_impl(PrtScene* s) {
     // is decided by the traversal stacks: 32 entries per lane (32 KB per block) leave it, the builders' bound of
     // PRT_STACK_DEPTH does not.  Most trees need far fewer entries than that bound (tree_stack_need).
     {
-        int need = PRT_STACK_DEPTH;
-        if (!s->bvh_info.built_on_device) {
-            need = s->bvh.stack_need;
-            if (need > PRT_STACK_SHALLOW && !s->bvh.nodes_shallow.empty()) {
-                // the same binary tree collapsed with the smaller budget (same leaf order: the records above fit both)
-                const int keep = s->fail_upload_at;
-                s->fail_upload_at = -1;
-                rc = s->up(s->bvh.nodes_shallow, &f.nodes);
-                s->fail_upload_at = keep;
-                if (rc) return rc;
-                f.n_nodes = (uint32_t)s->bvh.nodes_shallow.size();
-                need = PRT_STACK_SHALLOW;
-            }
-        } else {
-            std::vector<DNode> hn(d.n_nodes);
-            PRT_HIP(hipMemcpy(hn.data(), d.nodes, (size_t)d.n_nodes * sizeof(DNode), hipMemcpyDeviceToHost));
-            need = prt::tree_stack_need(hn.data(), hn.size());
+        const int need = s->stack_need; // of the tree K3 traverses (upload: the shallow collapse when the first one needs more than 32)
+        if (s->d_nodes_shallow) {
+            f.nodes = s->d_nodes_shallow;
+            f.n_nodes = s->n_nodes_shallow;
         }
         s->stack_depth32 = need <= PRT_STACK_SHALLOW ? PRT_STACK_SHALLOW : PRT_STACK_DEPTH;
         if (const char* e = std::getenv("PRT_TUNE_STACK32")) s->stack_depth32 = std::max(need, std::min(PRT_STACK_DEPTH, std::atoi(e))); // developer: smaller stacks when the tree allows
@@ -696,6 +717,14 @@ static int ensure_f32_impl(PrtScene* s) {
     s->blocks_per_cu32[0] = prt32::render_blocks_per_cu(false, s->feat, tables, s->stack_depth32, pad);
     s->blocks_per_cu32[1] = prt32::render_blocks_per_cu(true, s->feat, tables, s->stack_depth32, pad);
     s->f32_ready = true;
+    return PRT_OK;
+}
+
+// After the counters of a call slot have been zeroed: the pointers K3 reads from them (DCounters::pixel_list / trace).
+static int set_slot_pointers(PrtScene*, PrtScene::CallSlot& q, hipStream_t st, unsigned, const void* pixel_list, void* trace) {
+    if (!pixel_list && !trace) return PRT_OK; // zeroed already
+    const void* ptrs[2] = {pixel_list, trace};
+    PRT_HIP(hipMemcpyAsync(reinterpret_cast<char*>(q.d_ctr) + offsetof(DCounters, pixel_list), ptrs, sizeof(ptrs), hipMemcpyHostToDevice, st));
     return PRT_OK;
 }
 
@@ -895,6 +924,8 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.keep = s->feat == 0 ? 28 : 20;
     P.leaf_batch = s->feat == 0 ? 48 : 40;
     P.inner_min = s->feat == 0 ? 20 : 12;
+    P.cached_min = 24; // measured: veach-mis -1 %, the others flat
+    if (const char* e = std::getenv("PRT_TUNE_CACHED_MIN")) P.cached_min = std::atoi(e);
     if (const char* e = std::getenv("PRT_TUNE_KEEP")) P.keep = std::atoi(e);
     if (const char* e = std::getenv("PRT_TUNE_LEAF_BATCH")) P.leaf_batch = std::atoi(e);
     if (const char* e = std::getenv("PRT_TUNE_INNER_MIN")) P.inner_min = std::atoi(e);
@@ -913,7 +944,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.light_lds = s->light_lds;
     P.mat_lds = s->mat_lds;
     P.ltri_lds = s->ltri_lds;
-    P.stack_depth = PRT_STACK_DEPTH;
+    P.stack_depth = s->stack_depth;
     P.owned_tiles = P.n_tiles > P.rank ? (P.n_tiles - P.rank + P.nranks - 1) / P.nranks : 0;
     P.items_per_chunk = (uint64_t)P.owned_tiles * tile * tile;
     const bool count = count_work != 0;
@@ -995,6 +1026,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     if (P.n_items) {
         const uint64_t want = (P.n_items + PRT_BLOCK - 1) / PRT_BLOCK;
         const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)s->n_cu * bpc));
+        if ((rc = set_slot_pointers(s, q, st, grid, nullptr, nullptr))) return rc;
         if (f32) {
             // the same camera and parameters rounded to float (K5 below works from the fp64 originals: it only maps pixels)
             DCameraT<float> C32;
@@ -1009,14 +1041,14 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
             P32.seed_key = P.seed_key;
             P32.tile = P.tile; P32.tiles_x = P.tiles_x; P32.tiles_y = P.tiles_y; P32.n_tiles = P.n_tiles;
             P32.rank = P.rank; P32.nranks = P.nranks; P32.owned_tiles = P.owned_tiles; P32.jitter = P.jitter;
-            P32.keep = P.keep; P32.leaf_batch = P.leaf_batch; P32.inner_min = P.inner_min; P32.scramble = P.scramble;
+            P32.keep = P.keep; P32.leaf_batch = P.leaf_batch; P32.inner_min = P.inner_min; P32.scramble = P.scramble; P32.cached_min = P.cached_min;
             P32.light_lds = s->light_lds32; P32.mat_lds = s->mat_lds32; P32.ltri_lds = s->ltri_lds32;
             P32.stack_depth = s->stack_depth32;
             P32.items_per_chunk = P.items_per_chunk; P32.n_items = P.n_items;
             std::memcpy(P32.chunk_begin, P.chunk_begin, sizeof(P.chunk_begin));
             prt32::launch_render(s->d32, C32, P32, q.d_partial, q.d_ctr, count, s->feat, grid, st);
         } else {
-            prt::launch_render(s->d, C, P, q.d_partial, q.d_ctr, count, s->feat, grid, st);
+            prt::launch_render(s->d_k3, C, P, q.d_partial, q.d_ctr, count, s->feat, grid, st);
         }
         PRT_HIP(hipGetLastError());
     }
@@ -1100,6 +1132,7 @@ int prt_render_samples(PrtScene* s, const PrtCamera* cam, const PrtRenderParams*
     P.leaf_batch = s->feat == 0 ? 48 : 40;
     P.inner_min = s->feat == 0 ? 20 : 12;
     P.scramble = PRT_ITEMS_FROM_LIST;
+    P.cached_min = 65;
     for (int c = 0; c < 3; ++c) P.background[c] = p->background[c];
     P.seed_key = prt::seed_key(p->seed);
     P.tile = 8;
@@ -1111,7 +1144,7 @@ int prt_render_samples(PrtScene* s, const PrtCamera* cam, const PrtRenderParams*
     P.light_lds = s->light_lds;
     P.mat_lds = s->mat_lds;
     P.ltri_lds = s->ltri_lds;
-    P.stack_depth = PRT_STACK_DEPTH;
+    P.stack_depth = s->stack_depth;
     P.items_per_chunk = n_pixels;
     const bool count = trace != nullptr;
     const int bpc = s->blocks_per_cu[count ? 1 : 0];
@@ -1133,13 +1166,12 @@ int prt_render_samples(PrtScene* s, const PrtCamera* cam, const PrtRenderParams*
         PrtScene::CallSlot& q = *s->next_slot(nullptr, &we);
         if ((e = we) != hipSuccess) break;
         if ((e = hipMemsetAsync(q.d_ctr, 0, sizeof(DCounters), nullptr)) != hipSuccess) break;
-        const void* ptrs[2] = {d_pix, d_trace};
-        if ((e = hipMemcpy(reinterpret_cast<char*>(q.d_ctr) + offsetof(DCounters, pixel_list), ptrs, sizeof(ptrs), hipMemcpyHostToDevice)) != hipSuccess) break;
-        if (d_trace && (e = hipMemset(d_trace, 0, (size_t)P.n_items * PRT_TRACE_WORDS * sizeof(int32_t))) != hipSuccess) break;
-        (void)hipEventRecord(q.ev0, nullptr);
         const uint64_t want = (P.n_items + PRT_BLOCK - 1) / PRT_BLOCK;
         const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)s->n_cu * bpc));
-        if (P.max_depth >= 0) prt::launch_render(s->d, C, P, d_part, q.d_ctr, count, s->feat, grid, nullptr);
+        if (set_slot_pointers(s, q, nullptr, grid, d_pix, d_trace) != PRT_OK) { e = hipErrorUnknown; break; }
+        if (d_trace && (e = hipMemset(d_trace, 0, (size_t)P.n_items * PRT_TRACE_WORDS * sizeof(int32_t))) != hipSuccess) break;
+        (void)hipEventRecord(q.ev0, nullptr);
+        if (P.max_depth >= 0) prt::launch_render(s->d_k3, C, P, d_part, q.d_ctr, count, s->feat, grid, nullptr);
         else if ((e = hipMemset(d_part, 0, (size_t)P.n_items * 3 * sizeof(double))) != hipSuccess) break;
         if ((e = hipGetLastError()) != hipSuccess) break;
         (void)hipEventRecord(q.ev1, nullptr);

@@ -1083,20 +1083,24 @@ PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLig
 // ------------------------------------------------------------------ tile <-> pixel mapping (multi-GPU sharding)
 // Owned-pixel index -> pixel.  Tiles are dealt round-robin over ranks; inside a tile pixels are
 // visited in 8x8 blocks so the 64 lanes of a wave start on one compact block.
-PRT_DEV bool owned_to_pixel(const DRenderParams& P, const DCamera& C, uint32_t oi, int& px, int& py) {
-    if (P.scramble) oi = (uint32_t)(((uint64_t)oi * 2654435761ULL) % P.items_per_chunk); // experiment (odd multiplier; bijective for power-of-two counts)
-    const uint32_t tt = (uint32_t)(P.tile * P.tile);
+PRT_DEV bool tile_pixel(int scramble, uint32_t items_per_chunk, int tile, int tiles_x, int n_tiles, int rank, int nranks, int width,
+                        int height, uint32_t oi, int& px, int& py) {
+    if (scramble) oi = (uint32_t)(((uint64_t)oi * 2654435761ULL) % items_per_chunk); // experiment (odd multiplier; bijective for power-of-two counts)
+    const uint32_t tt = (uint32_t)(tile * tile);
     const uint32_t ot = oi / tt, w = oi - ot * tt;
-    uint32_t k = (uint32_t)P.rank + ot * (uint32_t)P.nranks;
-    if (k >= (uint32_t)P.n_tiles) return false;
+    uint32_t k = (uint32_t)rank + ot * (uint32_t)nranks;
+    if (k >= (uint32_t)n_tiles) return false;
     // tile slot k -> tile (tx, ty): every tile row is rotated by 3*ty so that the tiles of one rank
     // (k % nranks) form diagonals instead of fixed columns — better load balance across GPUs
-    const uint32_t ty = k / (uint32_t)P.tiles_x, kx = k - ty * (uint32_t)P.tiles_x;
-    const uint32_t tx = (kx + 3u * ty) % (uint32_t)P.tiles_x;
-    uint32_t bpr = (uint32_t)P.tile / 8u;
+    const uint32_t ty = k / (uint32_t)tiles_x, kx = k - ty * (uint32_t)tiles_x;
+    const uint32_t tx = (kx + 3u * ty) % (uint32_t)tiles_x;
+    uint32_t bpr = (uint32_t)tile / 8u;
     uint32_t blk = w / 64u, l = w % 64u;
     const uint32_t by = blk / bpr, bx = blk - by * bpr;
-    px = (int)(tx * P.tile + bx * 8u + (l % 8u));
-    py = (int)(ty * P.tile + by * 8u + (l / 8u));
-    return px < C.width && py < C.height;
+    px = (int)(tx * tile + bx * 8u + (l % 8u));
+    py = (int)(ty * tile + by * 8u + (l / 8u));
+    return px < width && py < height;
+}
+PRT_DEV bool owned_to_pixel(const DRenderParams& P, const DCamera& C, uint32_t oi, int& px, int& py) {
+    return tile_pixel(P.scramble, (uint32_t)P.items_per_chunk, P.tile, P.tiles_x, P.n_tiles, P.rank, P.nranks, C.width, C.height, oi, px, py);
 }

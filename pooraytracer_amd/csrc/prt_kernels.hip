@@ -37,7 +37,10 @@
 #else
 #define PRT_NS prt
 #endif
-#define PRT_DYN_STACK PRT_F32_TU // K3's traversal stacks in dynamic LDS, sized per launch (DRenderParams::stack_depth)
+#ifndef PRT_DYN_STACK64
+#define PRT_DYN_STACK64 0 // measured: a run-time depth costs the fp64 kernels 1.2 % (cornell) and buys them nothing (register-limited)
+#endif
+#define PRT_DYN_STACK (PRT_F32_TU || PRT_DYN_STACK64) // K3's traversal stacks in dynamic LDS, sized per launch from what the scene's tree can need (DRenderParams::stack_depth)
 
 // minimum resident waves per SIMD the register allocator must leave room for in K3
 #ifndef PRT_RENDER_WAVES
@@ -200,11 +203,10 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
 }
 
 // ------------------------------------------------------------------------------------------- K3
-enum : int { ST_FETCH = 0, ST_NEW_SAMPLE = 1, ST_CLOSEST = 2, ST_SHADOW = 3, ST_DONE = 4, ST_PRIMARY = 5 };
+enum : int { ST_FETCH = 0, ST_NEW_SAMPLE = 1, ST_CLOSEST = 2, ST_SHADOW = 3, ST_DONE = 4, ST_PRIMARY = 5, ST_CACHED = 6 };
 // The camera ray of a pixel is the same for every sample (Camera.cpp:53-57: GetRay once per pixel, no jitter): K3 traces
-// it ONCE per work item (ST_PRIMARY) and parks its hit — t, barycentrics, triangle — in LDS, lane-strided; every sample of
-// the item starts from that hit instead of re-tracing the identical ray.  PRT_PH_WORDS dwords per lane.
-#define PRT_PH_WORDS ((int)(3 * sizeof(real) / 4 + 1))
+// it ONCE per work item (ST_PRIMARY) and parks the ray's direction and its hit — t, triangle, barycentrics — in LDS,
+// lane-strided; every sample of the item starts from that hit (ST_CACHED) instead of re-tracing the identical ray.
 
 // Shading context of a hit, rebuilt from (incoming ray, HitInfo): HitRecord of Triangle::Hit
 // (Triangle.cpp:76-80,111) — position = ray(t), face-forwarded normal, tangent, uv.
@@ -234,18 +236,67 @@ PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 rd, real alpha, real beta, int32_t
     return c;
 }
 
+// A real number parked in / fetched from a lane's LDS column (`base` = the lane's slot of word 0, words PRT_BLOCK apart)
+PRT_DEV void park_real(uint32_t* base, int word, real v) {
+    if (PRT_F32) {
+        base[word * PRT_BLOCK] = __float_as_uint((float)v);
+    } else {
+        const unsigned long long b = (unsigned long long)__double_as_longlong((double)v);
+        base[word * PRT_BLOCK] = (uint32_t)b;
+        base[(word + 1) * PRT_BLOCK] = (uint32_t)(b >> 32);
+    }
+}
+PRT_DEV real unpark_real(const uint32_t* base, int word) {
+    if (PRT_F32) return (real)__uint_as_float(base[word * PRT_BLOCK]);
+    return (real)__longlong_as_double((long long)(((unsigned long long)base[(word + 1) * PRT_BLOCK] << 32) | base[word * PRT_BLOCK]));
+}
+#define PRT_RW ((int)(sizeof(real) / 4)) // dwords per real
+// a lane's parked camera ray and primary hit: t | triangle | direction[3] | (textured permutations) alpha, beta
+#define PARK_T 0
+#define PARK_TRI PRT_RW
+#define PARK_DIR (PRT_RW + 1)
+// Textured permutations do not park the direction: their LDS is spoken for (a deep tree's 40-entry stacks plus t, triangle
+// and barycentrics plus the material table fill a third of a CU), so they recompute it per sample from the camera, read on
+// demand (measured on bathroom2: parked in global memory +4.5 %, parked in LDS at the price of the 32-entry tree +2.5 %).
+#define PARK_DIR_GLOBAL(feat) (((feat) & PRT_FEAT_TEX) != 0)
+#define PARK_AB_AT(feat) (PARK_DIR_GLOBAL(feat) ? PRT_RW + 1 : 4 * PRT_RW + 1)
+#define PARK_WORDS(feat) (((feat) & PRT_FEAT_TEX) ? 3 * PRT_RW + 1 : 4 * PRT_RW + 1)
+
+// K3's arguments are ONE struct, so that the kernel can also reach them through the kernarg segment pointer: what the
+// hot loop needs (scene tables, thresholds, roulette, seed) is used as plain arguments — the compiler loads those into
+// scalar registers once — while everything only a work-item fetch or a miss needs (the camera, tile geometry, the chunk
+// table, the background, the output pointer: ~50 scalar registers) is read ON DEMAND through cold_args(), a pointer to the
+// same bytes that the compiler cannot see through: s_load at the point of use instead of values kept (and, beyond ~100
+// of them, spilled to VGPR lanes: 116 v_readlane per pass before this) across the whole traversal loop.
+struct RenderArgs {
+    DScene S;
+    DCamera C;
+    DRenderParams P;
+    double* partial;
+    DCounters* ctr;
+};
+typedef const RenderArgs __attribute__((address_space(4)))* ColdRenderArgs;
+PRT_DEV ColdRenderArgs cold_args() {
+    ColdRenderArgs q = (ColdRenderArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q)); // opaque from here on: loads through q stay where they are written
+    return q;
+}
+
 template <bool COUNT, int FEAT, bool LLDS, bool PAD>
-__global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
-    DScene S, DCamera C, DRenderParams P, double* __restrict__ partial, DCounters* ctr) {
+__global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(RenderArgs A) {
+    const DScene& S = A.S;
+    const DRenderParams& P = A.P; // hot fields only: see RenderArgs
+    DCounters* const ctr = A.ctr;
     __shared__ uint32_t s_qoff[PRT_BLOCK / 64];
     __shared__ unsigned long long s_rays[PRT_BLOCK / 64];
-    __shared__ uint32_t s_ph[(FEAT & PRT_FEAT_TEX) ? PRT_PH_WORDS : PRT_PH_WORDS - (int)(2 * sizeof(real) / 4)][PRT_BLOCK]; // the work item's primary hit (see ST_PRIMARY), read once per sample
+    __shared__ real s_center[4]; // Camera::center, the origin of every camera ray
+    __shared__ uint32_t s_park[PARK_WORDS(FEAT)][PRT_BLOCK]; // per lane: the work item's camera ray and its hit (ST_PRIMARY), read once per sample
+    uint32_t* const park = &s_park[0][threadIdx.x];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Dynamic LDS, sized by the host: the four waves' traversal stacks (P.stack_depth entries per lane, lane-strided),
-    // then the shading tables.  The depth is a launch parameter because it decides how many blocks a CU holds: a tree
-    // that needs at most 32 entries leaves room for a fourth block (the fp32 kernels have the registers for it).
-    // (The fp64 kernels sit at their register limit with three blocks per CU whatever the stacks take, so theirs stay
-    // a static array of PRT_STACK_DEPTH entries: a run-time depth cost them 6 more spilled scalar registers and 1 %.)
+    // then the shading tables.  The depth is a launch parameter: what the scene's tree can need, not the builders' bound of
+    // PRT_STACK_DEPTH — LDS left over decides how many blocks a CU holds (the fp32 kernels have the registers for a fourth
+    // block when a tree needs at most 32 entries) and leaves room for the parked camera rays.
     extern __shared__ __align__(16) unsigned char s_dyn_all[];
 #if PRT_DYN_STACK
     uint32_t* stk = reinterpret_cast<uint32_t*>(s_dyn_all) + (size_t)(wave * P.stack_depth) * 64 + lane;
@@ -259,6 +310,8 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
         s_qoff[wave] = 0;
         s_rays[wave] = 0ULL;
     }
+    if (threadIdx.x < 3) s_center[threadIdx.x] = A.C.center[threadIdx.x];
+    if (!LLDS) __syncthreads(); // (the LLDS kernels synchronise below, after staging their tables)
     // light tree in LDS (see sample_lights)
     const DLightNode* lds_lights = reinterpret_cast<const DLightNode*>(s_dyn);
     // ... followed by the whole material table (the host only selects LLDS when it fits): its fields are read
@@ -326,6 +379,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
     int state = ST_FETCH;
     uint32_t item = 0; // work items of a launch are counted in 32 bits (the host refuses more): every division below is a 32-bit one
     int px = 0, py = 0, s = 0, s_end = 0, depth = 0;
+    uint32_t pixel = 0; // j * W + i of the work item's pixel: the RNG key
     bool first = true, prev_skip = false;
     PST_ST(S_ACC, mk3(0, 0, 0));  // sum over this item's samples of colour * (1/spp)
     PST_ST(S_BETA, mk3(1, 1, 1)); // path throughput
@@ -360,69 +414,25 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
             // been consumed tr.o IS the shading point.
             bool have_fr = false;
             d3 fr_seen = mk3(0, 0, 0);
-            bool fresh = false; // a camera ray set up in this pass that has yet to be traced (pixel jitter only)
             if (state == ST_PRIMARY) {
-                // the item's camera ray has been traced: its hit serves every sample of the item
-                // (the barycentrics are only ever read for texture coordinates: untextured permutations keep t and the triangle)
-                uint32_t* ph = &s_ph[0][threadIdx.x];
-                if (PRT_F32) {
-                    ph[0] = __float_as_uint((float)tr.hit.t);
-                    ph[PRT_BLOCK] = (uint32_t)tr.hit.tri;
-                    if (FEAT & PRT_FEAT_TEX) {
-                        ph[2 * PRT_BLOCK] = __float_as_uint((float)tr.hit.alpha);
-                        ph[3 * PRT_BLOCK] = __float_as_uint((float)tr.hit.beta);
-                    }
-                } else {
-                    const unsigned long long a = (unsigned long long)__double_as_longlong((double)tr.hit.t);
-                    ph[0] = (uint32_t)a; ph[PRT_BLOCK] = (uint32_t)(a >> 32);
-                    ph[2 * PRT_BLOCK] = (uint32_t)tr.hit.tri;
-                    if (FEAT & PRT_FEAT_TEX) {
-                        const unsigned long long b = (unsigned long long)__double_as_longlong((double)tr.hit.alpha), c = (unsigned long long)__double_as_longlong((double)tr.hit.beta);
-                        ph[3 * PRT_BLOCK] = (uint32_t)b; ph[4 * PRT_BLOCK] = (uint32_t)(b >> 32);
-                        ph[5 * PRT_BLOCK] = (uint32_t)c; ph[6 * PRT_BLOCK] = (uint32_t)(c >> 32);
-                    }
+                // the item's camera ray has been traced: its hit serves every sample of the item (the barycentrics are only
+                // ever read for texture coordinates: untextured permutations keep t and the triangle)
+                park_real(park, PARK_T, tr.hit.t);
+                park[PARK_TRI * PRT_BLOCK] = (uint32_t)tr.hit.tri;
+                if (FEAT & PRT_FEAT_TEX) {
+                    park_real(park, PARK_AB_AT(FEAT), tr.hit.alpha);
+                    park_real(park, PARK_AB_AT(FEAT) + PRT_RW, tr.hit.beta);
                 }
-                state = ST_NEW_SAMPLE;
+                state = ST_NEW_SAMPLE; // set up at the bottom of this pass, consumed by the next one
             }
-            if (state == ST_NEW_SAMPLE) {
-                // per-sample stream keyed (seed, j*W+i, s); Camera::GetRay (Camera.cpp:108-117): pixel centre, no jitter
-                rng.seed_keyed(P.seed_key, (uint64_t)py * (uint64_t)C.width + (uint64_t)px, (uint64_t)s);
-                real fx = (real)px, fy = (real)py;
-                if (P.jitter) { // the disabled SampleSquare() offset of Camera.cpp:110-111, drawn per sample: y first (g++ argument order)
-                    fy += rng.next() - RL(0.5);
-                    fx += rng.next() - RL(0.5);
-                    fresh = true; // its own camera ray per sample: traced below, consumed by a later pass
-                } else {
-                    const uint32_t* ph = &s_ph[0][threadIdx.x];
-                    if (PRT_F32) {
-                        tr.hit.t = (real)__uint_as_float(ph[0]);
-                        tr.hit.tri = (int32_t)ph[PRT_BLOCK];
-                        if (FEAT & PRT_FEAT_TEX) {
-                            tr.hit.alpha = (real)__uint_as_float(ph[2 * PRT_BLOCK]);
-                            tr.hit.beta = (real)__uint_as_float(ph[3 * PRT_BLOCK]);
-                        }
-                    } else {
-                        tr.hit.t = (real)__longlong_as_double((long long)(((unsigned long long)ph[PRT_BLOCK] << 32) | ph[0]));
-                        tr.hit.tri = (int32_t)ph[2 * PRT_BLOCK];
-                        if (FEAT & PRT_FEAT_TEX) {
-                            tr.hit.alpha = (real)__longlong_as_double((long long)(((unsigned long long)ph[4 * PRT_BLOCK] << 32) | ph[3 * PRT_BLOCK]));
-                            tr.hit.beta = (real)__longlong_as_double((long long)(((unsigned long long)ph[6 * PRT_BLOCK] << 32) | ph[5 * PRT_BLOCK]));
-                        }
-                    }
-                }
-                const d3 ps = ld3(C.pixel00) + fx * ld3(C.du) + fy * ld3(C.dv);
-                tr.o = ld3(C.center);
-                tr.d = ps - tr.o;
-                PST_ST(S_BETA, mk3(1, 1, 1));
-                depth = P.max_depth;
-                first = true;
-                prev_skip = false;
-                state = ST_CLOSEST;
-            }
-            if (state == ST_CLOSEST && !fresh) {
+            if (state == ST_CACHED) state = ST_CLOSEST; // a sample set up by the previous pass from the parked hit: nothing to trace
+            if (state == ST_CLOSEST) {
                 if (tr.hit.tri < 0) {
                     // miss: background for the camera ray (Camera.cpp:127); with bSampleLights a bounce miss adds 0 (:187)
-                    if (first || !P.sample_lights) ADD_RADIANCE(ld3(P.background));
+                    if (first || !P.sample_lights) {
+                        const ColdRenderArgs q = cold_args();
+                        ADD_RADIANCE(mk3(q->P.background[0], q->P.background[1], q->P.background[2]));
+                    }
                     TRACE_VERTEX(-1);
                     end_sample = true;
                 } else {
@@ -532,7 +542,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 s++;
                 if (s < s_end) state = ST_NEW_SAMPLE;
                 else {
-                    double* o = partial + (size_t)item * 3;
+                    double* o = cold_args()->partial + (size_t)item * 3;
                     o[0] = (double)acc.x; // the partial sums are fp64 in either mode (K5 adds them in fp64)
                     o[1] = (double)acc.y;
                     o[2] = (double)acc.z;
@@ -542,6 +552,8 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
 
             // ---------------- give the lane its next piece of work
             if (state == ST_FETCH) {
+                const ColdRenderArgs q = cold_args(); // everything a fetch needs is read here, on demand
+                const uint32_t n_items = (uint32_t)q->P.n_items;
 #if PRT_ITEM_QUEUES > 1
                 // One returning atomic per wave and pass on the wave's current queue (the queue index is wave-uniform,
                 // so the compiler aggregates the lanes that execute it); a queue that hands out an index past the end
@@ -549,12 +561,12 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
                 // s_qoff[wave] = queues this wave has seen run dry.
                 {
                     uint32_t off = __builtin_amdgcn_readfirstlane(s_qoff[wave]);
-                    item = (uint32_t)P.n_items;
+                    item = n_items;
                     while (off < (uint32_t)PRT_ITEM_QUEUES) {
-                        const uint32_t q = (blockIdx.x + off) % (uint32_t)PRT_ITEM_QUEUES;
-                        const unsigned long long idx = atomicAdd(&ctr->queue[q * PRT_QUEUE_STRIDE], 1ULL);
-                        const unsigned long long it = ((idx >> 6) * PRT_ITEM_QUEUES + q) * 64ULL + (idx & 63ULL);
-                        if (it < P.n_items) {
+                        const uint32_t qi = (blockIdx.x + off) % (uint32_t)PRT_ITEM_QUEUES;
+                        const unsigned long long idx = atomicAdd(&ctr->queue[qi * PRT_QUEUE_STRIDE], 1ULL);
+                        const unsigned long long it = ((idx >> 6) * PRT_ITEM_QUEUES + qi) * 64ULL + (idx & 63ULL);
+                        if (it < n_items) {
                             item = (uint32_t)it;
                             break;
                         }
@@ -565,46 +577,97 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
 #else
                 {
                     const unsigned long long it = atomicAdd(&ctr->next_item, 1ULL); // per-lane fetch (the compiler aggregates lanes of one pass)
-                    item = it < P.n_items ? (uint32_t)it : (uint32_t)P.n_items;
+                    item = it < n_items ? (uint32_t)it : n_items;
                 }
 #endif
-                if (item >= (uint32_t)P.n_items) {
+                if (item >= n_items) {
                     state = ST_DONE;
 #if PRT_K3_TIMING
                     if (COUNT && tm_dry == 0) tm_dry = wall_clock64();
 #endif
                 } else {
-                    const uint32_t ipc = (uint32_t)P.items_per_chunk;
+                    const uint32_t ipc = (uint32_t)q->P.items_per_chunk;
                     const uint32_t chunk = item / ipc;
                     const uint32_t oi = item - chunk * ipc;
+                    const int W = q->C.width;
                     bool valid;
                     if (P.scramble == PRT_ITEMS_FROM_LIST) { // prt_render_samples: the pixels of a list
                         const int32_t pix = ctr->pixel_list[oi];
-                        py = pix / C.width;
-                        px = pix - py * C.width;
+                        py = pix / W;
+                        px = pix - py * W;
                         valid = true;
                         if (COUNT && ctr->trace != nullptr) ctr->trace[(size_t)item * PRT_TRACE_WORDS] = 0;
                     } else {
-                        valid = owned_to_pixel(P, C, oi, px, py);
+                        valid = tile_pixel(P.scramble, ipc, q->P.tile, q->P.tiles_x, q->P.n_tiles, q->P.rank, q->P.nranks, W, q->C.height, oi, px, py);
                     }
                     if (valid) {
-                        s = P.chunk_begin[chunk];
-                        s_end = P.chunk_begin[chunk + 1];
+                        s = q->P.chunk_begin[chunk];
+                        s_end = q->P.chunk_begin[chunk + 1];
+                        pixel = (uint32_t)(py * W + px);
                         PST_ST(S_ACC, mk3(0, 0, 0));
                         if (s >= s_end) {
-                            double* o = partial + (size_t)item * 3;
+                            double* o = q->partial + (size_t)item * 3;
                             o[0] = o[1] = o[2] = 0.0;
                         } else if (P.jitter) {
-                            state = ST_NEW_SAMPLE; // a camera ray of its own per sample: set up at the top of the next pass
+                            state = ST_NEW_SAMPLE; // a camera ray of its own per sample (below)
                         } else {
-                            // Camera::GetRay (Camera.cpp:108-117), once per work item: the pixel's one camera ray
-                            const d3 ps = ld3(C.pixel00) + (real)px * ld3(C.du) + (real)py * ld3(C.dv);
-                            tr.o = ld3(C.center);
+                            // Camera::GetRay (Camera.cpp:108-117), once per work item: the pixel's one camera ray.  Its direction
+                            // is parked next to the hit it is about to find.
+                            const d3 ps = mk3(q->C.pixel00[0], q->C.pixel00[1], q->C.pixel00[2]) + (real)px * mk3(q->C.du[0], q->C.du[1], q->C.du[2]) +
+                                          (real)py * mk3(q->C.dv[0], q->C.dv[1], q->C.dv[2]);
+                            tr.o = mk3(q->C.center[0], q->C.center[1], q->C.center[2]);
                             tr.d = ps - tr.o;
+                            if (!PARK_DIR_GLOBAL(FEAT)) {
+                                park_real(park, PARK_DIR, tr.d.x);
+                                park_real(park, PARK_DIR + PRT_RW, tr.d.y);
+                                park_real(park, PARK_DIR + 2 * PRT_RW, tr.d.z);
+                            }
                             state = ST_PRIMARY;
                         }
                     }
                 }
+            }
+            if (state == ST_NEW_SAMPLE) {
+                // per-sample stream keyed (seed, j*W+i, s)
+                rng.seed_keyed(P.seed_key, (uint64_t)pixel, (uint64_t)s);
+                if (P.jitter) {
+                    // the disabled SampleSquare() offset of Camera.cpp:110-111, drawn per sample: y first (g++ argument order);
+                    // a camera ray of its own, traced like any other
+                    const ColdRenderArgs q = cold_args();
+                    const int W = q->C.width;
+                    const int jy = (int)(pixel / (uint32_t)W), jx = (int)(pixel - (uint32_t)jy * (uint32_t)W);
+                    const real fy = (real)jy + (rng.next() - RL(0.5));
+                    const real fx = (real)jx + (rng.next() - RL(0.5));
+                    const d3 ps = mk3(q->C.pixel00[0], q->C.pixel00[1], q->C.pixel00[2]) + fx * mk3(q->C.du[0], q->C.du[1], q->C.du[2]) +
+                                  fy * mk3(q->C.dv[0], q->C.dv[1], q->C.dv[2]);
+                    tr.o = mk3(q->C.center[0], q->C.center[1], q->C.center[2]);
+                    tr.d = ps - tr.o;
+                    state = ST_CLOSEST;
+                } else {
+                    // Camera::GetRay gives every sample of the pixel the same ray (Camera.cpp:53-57, no jitter): the sample starts
+                    // from the parked hit of that ray.  Nothing to trace: the lane waits for the next pass, which consumes the hit
+                    // (the LDS reads below have the traversal rounds in between to arrive).
+                    tr.o = mk3(s_center[0], s_center[1], s_center[2]);
+                    if (PARK_DIR_GLOBAL(FEAT)) { // Camera::GetRay again (same expressions as at the fetch: the same bits)
+                        const ColdRenderArgs q = cold_args();
+                        const d3 ps = mk3(q->C.pixel00[0], q->C.pixel00[1], q->C.pixel00[2]) + (real)px * mk3(q->C.du[0], q->C.du[1], q->C.du[2]) +
+                                      (real)py * mk3(q->C.dv[0], q->C.dv[1], q->C.dv[2]);
+                        tr.d = ps - tr.o;
+                    } else {
+                        tr.d = mk3(unpark_real(park, PARK_DIR), unpark_real(park, PARK_DIR + PRT_RW), unpark_real(park, PARK_DIR + 2 * PRT_RW));
+                    }
+                    tr.hit.t = unpark_real(park, PARK_T);
+                    tr.hit.tri = (int32_t)park[PARK_TRI * PRT_BLOCK];
+                    if (FEAT & PRT_FEAT_TEX) {
+                        tr.hit.alpha = unpark_real(park, PARK_AB_AT(FEAT));
+                        tr.hit.beta = unpark_real(park, PARK_AB_AT(FEAT) + PRT_RW);
+                    }
+                    state = ST_CACHED;
+                }
+                PST_ST(S_BETA, mk3(1, 1, 1));
+                depth = P.max_depth;
+                first = true;
+                prev_skip = false;
             }
             PROF_MARK(3); // end of sample, item fetch, new sample
             // ---------------- start the traversal this lane needs next
@@ -626,6 +689,9 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(
             if (lane == 0) atomicAdd(&s_rays[wave], nc | (ns << 32));
         }
         if (__ballot(state != ST_DONE) == 0ULL) break;
+        // Lanes that started a sample from the parked hit have nothing to trace: with enough of them the next pass comes at
+        // once (it consumes their hits and hands them real rays) instead of after traversal rounds they would sit out.
+        if (wave_count(state == ST_CACHED) >= P.cached_min) continue;
 
         // ---------------- traversal steps until enough lanes have finished to be worth refilling
         do {
@@ -788,13 +854,13 @@ int render_permutation(int feat) {
 int render_lds_budget(int feat, int stack_depth) {
     int blocks = render_waves(render_permutation(feat));
     if (PRT_F32_TU && stack_depth <= 32) blocks = PRT_F32_WAVES > 4 && stack_depth <= 24 ? 5 : 4; // fp32: registers allow a fourth wave per SIMD when the stacks do
-    return ((160 * 1024 / blocks - (int)sizeof(uint32_t) * (stack_depth + PRT_PH_WORDS) * PRT_BLOCK - 128) / 512) * 512; // stacks + parked primary hits
+    return ((160 * 1024 / blocks - (int)sizeof(uint32_t) * (stack_depth + PARK_WORDS(render_permutation(feat))) * PRT_BLOCK - 256) / 512) * 512; // stacks + parked camera rays
 }
 size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds) {
     return (size_t)light_lds * sizeof(DLightNode) + (size_t)mat_lds * sizeof(DMaterial) + (size_t)ltri_lds * sizeof(DLightTri);
 }
 
-typedef void (*RenderKernel)(DScene, DCamera, DRenderParams, double*, DCounters*);
+typedef void (*RenderKernel)(RenderArgs);
 template <int FEAT, bool PAD>
 static RenderKernel render_kernel_feat(bool count, bool llds) {
     if (count) return llds ? k_render<true, FEAT, true, PAD> : k_render<true, FEAT, false, PAD>;
@@ -845,7 +911,13 @@ void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, do
     const size_t tables = render_table_bytes(P.light_lds, P.mat_lds, P.ltri_lds);
     const size_t dyn_lds = tables + stack_bytes(P.stack_depth);
     const bool pad = S.tri_stride == PRT_TRI_PAD_STRIDE(real) && sizeof(DTri) != PRT_TRI_PAD_STRIDE(real);
-    hipLaunchKernelGGL(render_kernel(count, feat, tables != 0, pad), dim3(grid), dim3(PRT_BLOCK), dyn_lds, st, S, C, P, d_partial, d_ctr);
+    RenderArgs A;
+    A.S = S;
+    A.C = C;
+    A.P = P;
+    A.partial = d_partial;
+    A.ctr = d_ctr;
+    hipLaunchKernelGGL(render_kernel(count, feat, tables != 0, pad), dim3(grid), dim3(PRT_BLOCK), dyn_lds, st, A);
 }
 
 #if PRT_F32_TU

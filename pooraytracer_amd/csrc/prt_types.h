@@ -209,6 +209,7 @@ struct DRenderParamsT {
     int32_t tile, tiles_x, tiles_y, n_tiles;
     int32_t rank, nranks, owned_tiles, jitter; // jitter: per-sample SampleSquare pixel offset (Camera.cpp:110-111)
     int32_t keep, leaf_batch, inner_min, scramble;
+    int32_t cached_min, pad0_;  // K3: with at least this many lanes holding a parked primary hit (ST_CACHED) the wave runs its next pass at once
     int32_t light_lds, mat_lds; // LLDS kernels: light-tree nodes / materials staged in (dynamic) LDS by K3
     int32_t ltri_lds;           // ... and ALL light triangles (n_lights) when there are at most 32 of them, else 0
     int32_t stack_depth;        // LDS traversal stack entries per lane of this launch (dynamic LDS): PRT_STACK_DEPTH, or less for a tree that needs less

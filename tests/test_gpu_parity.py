@@ -37,7 +37,7 @@ def compare_hits(g, o):
     assert np.isinf(g["t"][~hit]).all()
 
 
-def compare_images(gpu_img, cpu_img, max_bad_frac=1e-3):
+def compare_images(gpu_img, cpu_img, max_bad_frac=1e-4):  # observed since round 3: no pixel beyond 1e-9 anywhere
     tol = 1e-9 * np.maximum(1.0, np.abs(cpu_img))
     bad = (np.abs(gpu_img - cpu_img) > tol).any(axis=-1)
     assert bad.mean() <= max_bad_frac, f"{bad.sum()} of {bad.size} pixels differ"
@@ -831,3 +831,20 @@ def test_config5_frame_in_eight_tile_shares(gpu):
     assert covered.max() == 1
     rays = np.array(rays, dtype=np.float64)
     assert rays.max() / rays.min() <= 1.03, rays / rays.mean()
+
+
+def test_headline_rows_equal_the_oracle_on_every_pixel(gpu):
+    """The rows bench.py checks on the headline configuration (cornell-box 1024x1024 spp 500 depth 20): every pixel within
+    1e-9 of the oracle.  Rounds 1-2 tolerated 4-9 pixels here as 'knife-edge branch flips'; per-sample signatures
+    (prt_render_samples) showed identical paths with ONE different direct-light term each: the light pick's wrap-around
+    (test_light_pick_wraps_around_...), a parity bug, not a knife edge.  With it fixed nothing is left to tolerate."""
+    data = scenes.cornell_box()
+    cam = data.camera
+    sc = api.Scene(data).upload(gpu)
+    orc = oracle.Oracle(data)
+    y0, y1 = 456, 568
+    ref, _ = orc.render(spp=500, max_depth=20, seed=1, rows=(y0, y1), nthreads=16)
+    img = sc.render(spp=500, max_depth=20, seed=1)
+    rel = np.abs(img[y0:y1] - ref[y0:y1]) / np.maximum(1.0, np.abs(ref[y0:y1]))
+    assert (rel <= 1e-9).all(), (int((rel > 1e-9).any(-1).sum()), float(rel.max()))
+    assert rel.max() <= 1e-12   # observed 9e-15: summation order and last-bit arithmetic only

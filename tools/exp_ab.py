@@ -20,7 +20,7 @@ for name, fn, spp, depth in (("cornell", scenes.cornell_box, 250, 20), ("bathroo
         sc.render_device(None, fb.data_ptr(), max_depth=depth, spp=spp); torch.cuda.synchronize()
         c = sc.counters(); best = min(best, c["kernel_ms"])
     r = c["rays_closest"] + c["rays_shadow"]
-    txt = f"{name} {r/best/1e3:.0f}"
+    txt = f"{name} {best:.2f}ms {r/best/1e3:.0f}"
     if count:
         sc.render_device(None, fb.data_ptr(), max_depth=depth, spp=8, count_work=True); torch.cuda.synchronize()
         c = sc.counters(); r = c["rays_closest"] + c["rays_shadow"]

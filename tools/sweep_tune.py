@@ -8,19 +8,20 @@ tag = os.environ.get("PRT_LIB", "default").split("libprt_")[-1]
 keeps = [int(x) for x in os.environ.get("SW_KEEP", "16,20,24,28,32").split(",")]
 lbs = [int(x) for x in os.environ.get("SW_LB", "32").split(",")]
 ims = [int(x) for x in os.environ.get("SW_IM", "12").split(",")]
+cms = [int(x) for x in os.environ.get("SW_CM", "65").split(",")]
 for name, fn, spp, depth in (("cornell", scenes.cornell_box, 125, 20), ("bathroom", scenes.bathroom, 50, 50), ("veach", scenes.veach_mis, 200, 100)):
     data = fn(); sc = api.Scene(data).upload(0); cam = data.camera
     fb = torch.zeros((cam.height, cam.width, 3), dtype=torch.float32, device="cuda")
     sc.render_device(None, fb.data_ptr(), spp=4, max_depth=depth); torch.cuda.synchronize()
     res = []
-    for k, lb, im in itertools.product(keeps, lbs, ims):
-        os.environ["PRT_TUNE_KEEP"], os.environ["PRT_TUNE_LEAF_BATCH"], os.environ["PRT_TUNE_INNER_MIN"] = str(k), str(lb), str(im)
+    for k, lb, im, cm in itertools.product(keeps, lbs, ims, cms):
+        os.environ["PRT_TUNE_KEEP"], os.environ["PRT_TUNE_LEAF_BATCH"], os.environ["PRT_TUNE_INNER_MIN"], os.environ["PRT_TUNE_CACHED_MIN"] = str(k), str(lb), str(im), str(cm)
         best = 1e9
         for _ in range(2):
             sc.render_device(None, fb.data_ptr(), max_depth=depth, spp=spp); torch.cuda.synchronize()
             c = sc.counters(); best = min(best, c["kernel_ms"])
         r = c["rays_closest"] + c["rays_shadow"]
-        res.append((r / best / 1e3, k, lb, im))
-    res.sort(reverse=True)
-    print(tag, name, " ".join(f"{m:.0f}@k{k}/lb{lb}/im{im}" for m, k, lb, im in res[:12]), "| worst", f"{res[-1][0]:.0f}", flush=True)
+        res.append((best, k, lb, im, cm))
+    res.sort()
+    print(tag, name, " ".join(f"{m:.2f}ms@k{k}/lb{lb}/im{im}/cm{cm}" for m, k, lb, im, cm in res[:14]), "| worst", f"{res[-1][0]:.2f}", flush=True)
     del sc

@@ -3,8 +3,8 @@
 //   hipcc -O3 --offload-arch=gfx950 tools/valu_calib.hip -o tools/valu_calib && tools/valu_calib > profiles/r03_valu_calibration.json
 // Every kernel runs ITER x 128 INDEPENDENT instructions of one kind (16 accumulators, so no instruction waits for the one
 // before it) per wave, brackets them with s_memtime (shader cycles) and reports wave-instructions per cycle per SIMD =
-// waves per SIMD x instructions / cycles.  k waves per SIMD = k workgroups of 256 threads per CU, pinned by giving each
-// workgroup 1/k of the CU's LDS and launching exactly CUs x k of them.
+// waves per SIMD x instructions / cycles.  k waves per SIMD = ONE workgroup of 256 k threads per CU (its waves are dealt
+// round-robin over the CU's four SIMDs), pinned by giving the workgroup all of the CU's LDS and launching exactly one per CU.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -47,7 +47,7 @@ static const char* kNames[N_OPS] = {
         else if (OP == ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %0, %1" : "+v"(a) : "v"(x));                     \
         else if (OP == MAX_F32) asm volatile("v_max_f32 %0, %1, %0" : "+v"(a) : "v"(x));                               \
         else if (OP == MAX3_F32) asm volatile("v_max3_f32 %0, %1, %2, %0" : "+v"(a) : "v"(x), "v"(y));                 \
-        else if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(x));                      \
+        else if (OP == CNDMASK) asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[22:23]" : "+v"(a) : "v"(x));            \
         else if (OP == CMP_LE_F32) asm volatile("v_cmp_le_f32 vcc, %0, %1" : : "v"(a), "v"(x) : "vcc");                \
         else if (OP == MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a) : "v"(x));                         \
         else if (OP == XOR_B32) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a) : "v"(x));                               \
@@ -67,7 +67,7 @@ static const char* kNames[N_OPS] = {
     } while (0)
 
 template <int OP>
-__global__ __launch_bounds__(256) void k_issue(unsigned long long* cycles, float* sink, float seed) {
+__global__ __launch_bounds__(1024) void k_issue(unsigned long long* cycles, float* sink, float seed) {
     extern __shared__ unsigned char lds[]; // only to pin the number of workgroups a CU holds
     float a[16];
     double d[16];
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void k_issue(unsigned long long* cycles, float
         d[i] = (double)seed + (double)(threadIdx.x * 3 + i);
     }
     if (threadIdx.x == 1023) lds[0] = 1;
+    asm volatile("s_mov_b64 s[22:23], 0x5555" : : : "s22", "s23"); // the lane mask v_cndmask selects by
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITER; ++it) {
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void k_issue(unsigned long long* cycles, float
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += a[i] + (float)d[i];
     if (s == 1.2345f) sink[0] = s;
-    if ((threadIdx.x & 63) == 0) cycles[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) cycles[(size_t)blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
 typedef void (*Kern)(unsigned long long*, float*, float);
@@ -111,7 +112,7 @@ int main() {
     fill<0>(kern);
     unsigned long long* d_cyc = nullptr;
     float* d_sink = nullptr;
-    CK(hipMalloc(&d_cyc, sizeof(unsigned long long) * (size_t)n_cu * 4 * 4));
+    CK(hipMalloc(&d_cyc, sizeof(unsigned long long) * (size_t)n_cu * 16));
     CK(hipMalloc(&d_sink, 16));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -121,31 +122,45 @@ int main() {
     for (int op = 0; op < N_OPS; ++op) {
         std::printf("  \"%s\": {", kNames[op]);
         for (int k = 1; k <= 4; ++k) {
-            const int lds = std::min(160 * 1024 / k - 1024, 160 * 1024 - 1024) / 256 * 256;
+            const int lds = 160 * 1024 - 1024; // the whole CU: one workgroup per CU
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern[op]), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
                 std::fprintf(stderr, "cannot request %d bytes of LDS per workgroup\n", lds);
                 return 1;
             }
-            const int grid = n_cu * k;
+            const int grid = n_cu, block = 256 * k;
             float best_ms = 1e30f;
-            std::vector<unsigned long long> cyc((size_t)grid * 4);
+            std::vector<unsigned long long> cyc((size_t)grid * 4 * k);
             double med = 0;
             for (int rep = 0; rep < 3; ++rep) {
                 CK(hipEventRecord(e0));
-                hipLaunchKernelGGL(kern[op], dim3(grid), dim3(256), lds, 0, d_cyc, d_sink, 0.0f);
+                hipLaunchKernelGGL(kern[op], dim3(grid), dim3(block), lds, 0, d_cyc, d_sink, 0.0f);
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
                 float ms = 0;
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 if (ms < best_ms) {
                     best_ms = ms;
-                    CK(hipMemcpy(cyc.data(), d_cyc, cyc.size() * 8, hipMemcpyDeviceToHost));
+                    std::vector<unsigned long long> all((size_t)n_cu * 16);
+                    CK(hipMemcpy(all.data(), d_cyc, all.size() * 8, hipMemcpyDeviceToHost));
+                    cyc.clear();
+                    for (int b = 0; b < grid; ++b)
+                        for (int w = 0; w < 4 * k; ++w) cyc.push_back(all[(size_t)b * 16 + w]);
                     std::sort(cyc.begin(), cyc.end());
-                    med = (double)cyc[cyc.size() / 2];
+                    // per SIMD: the waves of one SIMD share it unevenly (the older wave issues first), so what the SIMD issued
+                    // per cycle is all its waves' instructions over the LONGEST of their times; median over the SIMDs
+                    std::vector<unsigned long long> worst;
+                    for (int b = 0; b < grid; ++b)
+                        for (int sd = 0; sd < 4; ++sd) {
+                            unsigned long long m = 0;
+                            for (int w = sd; w < 4 * k; w += 4) m = std::max(m, all[(size_t)b * 16 + w]);
+                            worst.push_back(m);
+                        }
+                    std::sort(worst.begin(), worst.end());
+                    med = (double)worst[worst.size() / 2];
                 }
             }
             const double per_cycle = (double)k * ITER * 128 / med;
-            std::printf("%s\"w%d\": {\"per_cycle_per_simd\": %.4f, \"cycles_per_instruction\": %.3f, \"clock_ghz\": %.3f, \"spread\": %.3f}", k == 1 ? "" : ", ", k,
+            std::printf("%s\"w%d\": {\"per_cycle_per_simd\": %.4f, \"cycles_per_instruction\": %.3f, \"clock_ghz\": %.3f, \"wave_time_max_over_min\": %.3f}", k == 1 ? "" : ", ", k,
                         per_cycle, 1.0 / per_cycle, med / (best_ms * 1e6), (double)cyc.back() / (double)cyc.front());
         }
         std::printf("}%s\n", op + 1 < N_OPS ? "," : "");
