@@ -45,7 +45,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0    # MI355X HBM3E nominal (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 N_SIMD = 256 * 4          # 256 CUs x 4 SIMDs
 PEAK_CLOCK_GHZ = 2.4
-VALU_PEAK_GINST = N_SIMD * PEAK_CLOCK_GHZ / 4.0  # one wave64 VALU instruction per SIMD per 4 cycles = 614.4 G/s
+# The `valu` roofline's denominator is MEASURED: tools/valu_calib.hip times every vector instruction the kernels are made of
+# at 1-4 waves per SIMD (profiles/r03_valu_calibration.json: plain fp32 / integer ALU ops issue every ~2.2-2.6 cycles per
+# SIMD, everything else K1 / K3 use — fp64, conversions, v_alignbit, min / max, v_cndmask, compares, v_pk_fma_f32 — every
+# ~4.2, reciprocals 8-16), tools/price_mix.py prices each permutation's ISA with that, weighted by the wave-level counters
+# of the counting build (profiles/r03_valu_mix.json).  Fallback when that file has no entry: 4.2 cycles per instruction.
+VALU_FALLBACK_GINST = N_SIMD * PEAK_CLOCK_GHZ / 4.2
+
+
+def valu_peak(workload):
+    try:
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_mix.json")))["workloads"]
+        e = mix.get(workload) or mix.get(workload.split("-spp")[0] + ("-f32" if workload.endswith("-f32") else ""))
+        if e:
+            return float(e["issue_ceiling_ginstr_per_s"]), float(e["avg_cycles_per_valu_instruction"]), "profiles/r03_valu_mix.json"
+    except Exception:
+        pass
+    return VALU_FALLBACK_GINST, 4.2, "fallback: 4.2 cycles per vector instruction (profiles/r03_valu_calibration.json, fp64 / conversion class)"
 
 WORKLOADS = {
     # name: (scene factory name, kwargs, spp, depth)
@@ -186,9 +202,10 @@ def roofline(workload, kernel, bpr, npr, tpr, fpr, rays_per_launch, extra_bytes,
                        random_line_ceiling_per_s=round(ceiling / 1e9, 2), frac_of_line_ceiling=round(lines_per_s / ceiling, 4))
     elif valu is not None:
         ginst = valu / sec / 1e9
-        out.update(bound="valu", achieved=round(ginst, 1), peak=round(VALU_PEAK_GINST, 1), unit="Ginstr/s",
-                   frac=round(ginst / VALU_PEAK_GINST, 4), traffic=traffic,
-                   valu_insts_per_ray=round(valu / rays_per_launch, 2))
+        peak, cyc, src = valu_peak(workload)
+        out.update(bound="valu", achieved=round(ginst, 1), peak=round(peak, 1), unit="Ginstr/s",
+                   frac=round(ginst / peak, 4), traffic=traffic,
+                   valu_insts_per_ray=round(valu / rays_per_launch, 2), peak_cycles_per_instruction=cyc, peak_source=src)
     else:  # no counters for this build yet: the algorithmic figure only, flagged
         out.update(bound="hbm", achieved=round(alg_gbps, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                    frac=round(alg_gbps / HBM_PEAK_GBPS, 4), traffic=None, note="no PMC summary for this workload")

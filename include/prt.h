@@ -163,18 +163,18 @@ typedef struct PrtLightSample {
 } PrtLightSample;
 
 typedef struct PrtCounters {
-    uint64_t rays_closest;  /* camera + continuation traversals */
+    uint64_t rays_closest;  /* camera + continuation traversals executed (the camera ray of a pixel is traced once per work item, not per sample) */
     uint64_t rays_shadow;   /* NEE visibility traversals */
     uint64_t node_fetches;  /* BVH node records read (counting runs only; PrtBvhInfo.node_bytes each) */
-    uint64_t tri_tests;     /* triangle plane / interval tests = first 64 bytes of a 128-byte record (counting runs only) */
-    uint64_t samples;       /* camera samples started */
+    uint64_t tri_tests;     /* triangle plane / interval tests = the first 32 bytes (n, D) of a 96-byte record (counting runs only) */
+    uint64_t samples;       /* camera samples of the call (pixels rendered x spp) */
     double kernel_ms;       /* hipEvent time of the dominant kernel of the last call */
     uint64_t bvh_nodes;     /* static: nodes in the flattened tree */
     uint64_t bvh_depth;     /* static: max depth */
     uint64_t inner_rounds;  /* counting runs: wave-level node-visit rounds (64 lanes each) */
     uint64_t leaf_rounds;   /* counting runs: wave-level leaf rounds */
     uint64_t refills;       /* counting runs: wave-level shade/refill passes */
-    uint64_t tri_full;      /* counting runs: tests that passed the interval check and fetched the second 64 bytes */
+    uint64_t tri_full;      /* counting runs: tests that passed the interval check and fetched the 64 bytes of edge functions */
 } PrtCounters;
 
 /* Which builder made the traversal BVH and what it cost. */

@@ -1017,6 +1017,9 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
         q.partial_cap = need;
     }
     const size_t npx = (size_t)C.width * C.height * 3;
+    void* dump_buf = nullptr;
+    unsigned long long dump_cap = 0;
+    std::string dump_path;
     PRT_HIP(hipMemsetAsync(q.d_ctr, 0, sizeof(DCounters), st));
     if (d_rgb_f64) PRT_HIP(hipMemsetAsync(d_rgb_f64, 0, npx * sizeof(double), st));
     if (d_rgb_f32) PRT_HIP(hipMemsetAsync(d_rgb_f32, 0, npx * sizeof(float), st));
@@ -1027,6 +1030,17 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
         const uint64_t want = (P.n_items + PRT_BLOCK - 1) / PRT_BLOCK;
         const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)s->n_cu * bpc));
         if ((rc = set_slot_pointers(s, q, st, grid, nullptr, nullptr))) return rc;
+        if (const char* e = std::getenv("PRT_TUNE_DUMP_RAYS")) { // "<max rays>,<file>" (counting launches only)
+            const std::string v(e);
+            const size_t comma = v.find(',');
+            if (count && comma != std::string::npos) {
+                dump_cap = std::strtoull(v.substr(0, comma).c_str(), nullptr, 10);
+                dump_path = v.substr(comma + 1);
+                PRT_HIP(hipMalloc(&dump_buf, (size_t)dump_cap * sizeof(PrtRay)));
+                const unsigned long long vals[3] = {(unsigned long long)(uintptr_t)dump_buf, dump_cap, 0ULL};
+                PRT_HIP(hipMemcpyAsync(reinterpret_cast<char*>(q.d_ctr) + offsetof(DCounters, ray_dump), vals, sizeof(vals), hipMemcpyHostToDevice, st));
+            }
+        }
         if (f32) {
             // the same camera and parameters rounded to float (K5 below works from the fp64 originals: it only maps pixels)
             DCameraT<float> C32;
@@ -1053,6 +1067,20 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
         PRT_HIP(hipGetLastError());
     }
     PRT_HIP(hipEventRecord(q.ev1, st));
+    if (dump_buf) { // developer experiment: write K3's ray stream to the file (synchronous)
+        PRT_HIP(hipStreamSynchronize(st));
+        DCounters h;
+        PRT_HIP(hipMemcpy(&h, q.d_ctr, sizeof(h), hipMemcpyDeviceToHost));
+        const size_t nd = (size_t)std::min<unsigned long long>(h.ray_dump_n, dump_cap);
+        std::vector<PrtRay> rays(nd);
+        PRT_HIP(hipMemcpy(rays.data(), dump_buf, nd * sizeof(PrtRay), hipMemcpyDeviceToHost));
+        (void)hipFree(dump_buf);
+        if (FILE* f = std::fopen(dump_path.c_str(), "wb")) {
+            std::fwrite(rays.data(), sizeof(PrtRay), nd, f);
+            std::fclose(f);
+        }
+        std::fprintf(stderr, "[prt] dumped %zu of %llu rays to %s\n", nd, h.ray_dump_n, dump_path.c_str());
+    }
     if (P.n_items) {
         prt::launch_finalize(C, P, q.d_partial, static_cast<double*>(d_rgb_f64), static_cast<float*>(d_rgb_f32), st);
         PRT_HIP(hipGetLastError());

@@ -1,8 +1,9 @@
 // prt_device.h — device functions of the gfx950 path tracer (wave64, fp64 arithmetic).
 //
-// Everything here is written for CDNA4 directly: per-lane BVH2 traversal with a lane-strided LDS
-// stack (conflict-free: entry e of lane l lives at word e*64+l), 32-byte node records with both children's
-// boxes on a 16-bit grid (or 64-byte 4-wide nodes, PRT_BVH_WIDTH), 128-byte fp64 triangle records, fp64 shading.
+// Everything here is written for CDNA4 directly: per-lane traversal of a 4-wide BVH (64-byte nodes: four children's
+// boxes on a 16-bit grid; PRT_BVH_WIDTH 2 keeps the 32-byte binary node for A/B) with a lane-strided LDS stack
+// (conflict-free: entry e of lane l lives at word e*64+l), 96-byte fp64 triangle records (plane + two edge functions;
+// 48 bytes in the fp32 translation unit), shading in the scalar type of the translation unit.
 //
 // Reference behaviour followed by each function is cited as file:line of Zoz4/Pooraytracer.
 #pragma once

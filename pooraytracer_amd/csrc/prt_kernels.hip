@@ -8,7 +8,7 @@
 //
 // K3 design (MI355X: 256 CUs x 4 SIMD, wave64, 160 KB LDS/CU, per-XCD L2):
 //   * persistent workgroups (grid = CUs x resident blocks); every LANE owns one work item =
-//     (pixel, sample chunk) and pulls the next one from a global atomic counter when it finishes, so
+//     (pixel, sample chunk) and pulls the next one from one of 16 global atomic counters when it finishes, so
 //     short paths (light / background pixels) never idle a wave for long — lane-level regeneration
 //     instead of a per-bounce compaction pass;
 //   * traversal is resumable per lane (Trav::step = one node visit or one leaf).  A wave steps all
@@ -17,7 +17,8 @@
 //     Russian roulette / Scatter / next sample / next item) and start their next ray — continuation
 //     or shadow, whichever that path needs — while the others keep their stack and resume.  Lanes
 //     never wait for the slowest ray of the wave, and there is a single traversal call site;
-//     shadow rays use closest-hit semantics with a certain-occluder early-out;
+//     shadow rays are any-hit rays over [0.001, dist - 0.001] (what Camera.cpp:150-155's test amounts to);
+//   * the camera ray of a pixel is traced once per work item; every sample starts from its parked hit;
 //   * traversal stack in LDS, lane-strided (conflict-free), PRT_STACK_DEPTH entries per lane;
 //   * results are deterministic: per-sample keyed RNG, per-item partial sums combined in a fixed
 //     order by K5 (no float atomics on the framebuffer).
@@ -268,13 +269,15 @@ PRT_DEV real unpark_real(const uint32_t* base, int word) {
 // table, the background, the output pointer: ~50 scalar registers) is read ON DEMAND through cold_args(), a pointer to the
 // same bytes that the compiler cannot see through: s_load at the point of use instead of values kept (and, beyond ~100
 // of them, spilled to VGPR lanes: 116 v_readlane per pass before this) across the whole traversal loop.
-struct RenderArgs {
-    DScene S;
-    DCamera C;
-    DRenderParams P;
+template <typename R> // (the scalar type shows in the kernel's name: profiles tell the fp64 launch from the fp32 one by it)
+struct RenderArgsT {
+    DSceneT<R> S;
+    DCameraT<R> C;
+    DRenderParamsT<R> P;
     double* partial;
     DCounters* ctr;
 };
+typedef RenderArgsT<real> RenderArgs;
 typedef const RenderArgs __attribute__((address_space(4)))* ColdRenderArgs;
 PRT_DEV ColdRenderArgs cold_args() {
     ColdRenderArgs q = (ColdRenderArgs)__builtin_amdgcn_kernarg_segment_ptr();
@@ -415,8 +418,41 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
             bool have_fr = false;
             d3 fr_seen = mk3(0, 0, 0);
             if (state == ST_PRIMARY) {
-                // the item's camera ray has been traced: its hit serves every sample of the item (the barycentrics are only
-                // ever read for texture coordinates: untextured permutations keep t and the triangle)
+                // The item's camera ray has been traced.  If it left the scene or met an emitter, every sample of the item is
+                // that one radiance (Camera.cpp:127,129-132: no random number is drawn): the item's samples are added up
+                // right here, in the order and with the operations ADD_RADIANCE would use one pass at a time (same bits),
+                // and the lane moves on to its next item instead of sitting through one pass per sample.
+                bool flat = false;
+                d3 x = mk3(0, 0, 0);
+                // (Measured: veach-mis -2.0 %, where many pixels look at a light or past the scene; cornell +0.7 %, bathroom2 +-0 —
+                // so only the permutations with glossy materials carry it.  prt_render_samples keeps the per-sample flow.)
+                if ((FEAT & (PRT_FEAT_PHONG | PRT_FEAT_CT)) && P.scramble != PRT_ITEMS_FROM_LIST) {
+                    if (tr.hit.tri < 0) {
+                        const ColdRenderArgs q = cold_args();
+                        x = mk3(q->P.background[0], q->P.background[1], q->P.background[2]);
+                        flat = true;
+                    } else {
+                        const DMaterial& m = MATERIAL(S.shade[tr.hit.tri].material);
+                        if (m.has_emission) {
+                            x = ld3(m.emission);
+                            flat = true;
+                        }
+                    }
+                }
+                if (flat) {
+                    const d3 term = (mk3(1, 1, 1) * x) * inv_spp; // throughput 1 at the camera vertex
+                    d3 acc = PST_LD(S_ACC);
+                    for (; s < s_end; ++s) acc = acc + term;
+                    double* o = cold_args()->partial + (size_t)item * 3;
+                    o[0] = (double)acc.x;
+                    o[1] = (double)acc.y;
+                    o[2] = (double)acc.z;
+                    state = ST_FETCH;
+                }
+            }
+            if (state == ST_PRIMARY) {
+                // its hit serves every sample of the item (the barycentrics are only ever read for texture coordinates:
+                // untextured permutations keep t and the triangle)
                 park_real(park, PARK_T, tr.hit.t);
                 park[PARK_TRI * PRT_BLOCK] = (uint32_t)tr.hit.tri;
                 if (FEAT & PRT_FEAT_TEX) {
@@ -680,6 +716,17 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
                 // boxes beyond the light are culled from the start and traversal stops at the first accepted triangle.
                 const bool sh_ray = state == ST_SHADOW;
                 started = sh_ray ? 2 : 1;
+                if (COUNT && ctr->ray_dump != nullptr) { // developer experiment: K3's own ray stream, for K1 to replay
+                    const unsigned long long k = atomicAdd(&ctr->ray_dump_n, 1ULL);
+                    if (k < ctr->ray_dump_cap) {
+                        PrtRay r;
+                        r.o[0] = (double)tr.o.x; r.o[1] = (double)tr.o.y; r.o[2] = (double)tr.o.z;
+                        r.d[0] = (double)tr.d.x; r.d[1] = (double)tr.d.y; r.d[2] = (double)tr.d.z;
+                        r.tmin = sh_ray ? 0.001 : 0.0001;
+                        r.tmax = sh_ray ? (double)(ldist - RL(0.001)) : __builtin_huge_val();
+                        static_cast<PrtRay*>(ctr->ray_dump)[k] = r;
+                    }
+                }
                 tr.start(S, sh_ray ? RL(0.001) : RL(0.0001), sh_ray ? ldist - RL(0.001) : PRT_INF);
             }
         }

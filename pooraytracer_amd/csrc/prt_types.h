@@ -239,6 +239,9 @@ struct DCounters {
     // (index j*W+i); the counting instantiation also writes each item's path signature to trace[item * PRT_TRACE_WORDS]
     const int32_t* pixel_list;
     int32_t* trace;
-    unsigned long long pad_[PRT_QUEUE_STRIDE - 12];
+    // developer experiment (PRT_TUNE_DUMP_RAYS, counting instantiation): every traversal K3 starts is appended here as a PrtRay
+    void* ray_dump;
+    unsigned long long ray_dump_cap, ray_dump_n;
+    unsigned long long pad_[PRT_QUEUE_STRIDE - 15];
     unsigned long long queue[PRT_ITEM_QUEUES * PRT_QUEUE_STRIDE]; // queue[q * PRT_QUEUE_STRIDE] = next 64-item-block-local index of queue q
 };

@@ -23,7 +23,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 kernel_key = "k_trace_closest<false" if workload.startswith("s") and "rays" in workload else "k_render<false"
-scene_key = "DSceneT<float>" if workload.endswith("-f32") else "DSceneT<double>"  # the fp32 workloads also render one fp64 frame (their parity check)
+scene_key = "T<float>" if workload.endswith("-f32") else "T<double>"  # DSceneT<..> (K1) / RenderArgsT<..> (K3); the fp32 workloads also render one fp64 frame (their parity check)
 
 
 def timed(name):
