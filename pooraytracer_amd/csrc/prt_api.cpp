@@ -571,6 +571,9 @@ static int upload_impl(PrtScene* s, int device) {
     const bool pad = d.tri_stride == PRT_TRI_PAD_STRIDE(double) && sizeof(DTri) != PRT_TRI_PAD_STRIDE(double);
     s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat, tables, s->stack_depth, pad);
     s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, tables, s->stack_depth, pad);
+    if (std::getenv("PRT_TUNE_VERBOSE"))
+        std::fprintf(stderr, "[prt] fp64 render kernels: %d blocks per CU, LDS tables: %d materials, %d light triangles, %d light nodes\n",
+                     s->blocks_per_cu[0], s->mat_lds, s->ltri_lds, s->light_lds);
     return PRT_OK;
 }
 
@@ -701,10 +704,21 @@ static int ensure_f32_impl(PrtScene* s) {
     // is decided by the traversal stacks: 32 entries per lane (32 KB per block) leave it, the builders' bound of
     // PRT_STACK_DEPTH does not.  Most trees need far fewer entries than that bound (tree_stack_need).
     {
-        const int need = s->stack_need; // of the tree K3 traverses (upload: the shallow collapse when the first one needs more than 32)
+        int need = s->stack_need; // of the tree the fp64 K3 traverses
+        if (need > PRT_STACK_SHALLOW && !s->d_nodes_shallow && !s->bvh_info.built_on_device && !s->bvh.nodes_shallow.empty()) {
+            // the same binary tree collapsed for 32 entries (same leaf order: the records above fit both): the fp32 kernels
+            // have the registers for a fourth block per CU, which 32-entry stacks leave the LDS for
+            const int keep = s->fail_upload_at;
+            s->fail_upload_at = -1;
+            rc = s->up(s->bvh.nodes_shallow, &s->d_nodes_shallow);
+            s->fail_upload_at = keep;
+            if (rc) return rc;
+            s->n_nodes_shallow = (uint32_t)s->bvh.nodes_shallow.size();
+        }
         if (s->d_nodes_shallow) {
             f.nodes = s->d_nodes_shallow;
             f.n_nodes = s->n_nodes_shallow;
+            need = std::min(need, PRT_STACK_SHALLOW);
         }
         s->stack_depth32 = need <= PRT_STACK_SHALLOW ? PRT_STACK_SHALLOW : PRT_STACK_DEPTH;
         if (const char* e = std::getenv("PRT_TUNE_STACK32")) s->stack_depth32 = std::max(need, std::min(PRT_STACK_DEPTH, std::atoi(e))); // developer: smaller stacks when the tree allows
@@ -716,6 +730,9 @@ static int ensure_f32_impl(PrtScene* s) {
     const bool pad = stride == PRT_TRI_PAD_STRIDE(float) && sizeof(DTriT<float>) != PRT_TRI_PAD_STRIDE(float);
     s->blocks_per_cu32[0] = prt32::render_blocks_per_cu(false, s->feat, tables, s->stack_depth32, pad);
     s->blocks_per_cu32[1] = prt32::render_blocks_per_cu(true, s->feat, tables, s->stack_depth32, pad);
+    if (std::getenv("PRT_TUNE_VERBOSE"))
+        std::fprintf(stderr, "[prt] fp32 render kernels: %d blocks per CU, stacks %d, LDS tables: %d materials, %d light triangles, %d light nodes\n",
+                     s->blocks_per_cu32[0], s->stack_depth32, s->mat_lds32, s->ltri_lds32, s->light_lds32);
     s->f32_ready = true;
     return PRT_OK;
 }

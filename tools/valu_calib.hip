@@ -27,12 +27,14 @@ constexpr int ITER = 2048;
 enum Op : int {
     FMA_F32, PK_FMA_F32, FMA_F64, MUL_F64, ADD_F64, CVT_F32_U32, CVT_F32_U32_SDWA, ALIGNBIT, MAX_F32, MAX3_F32, CNDMASK, CMP_LE_F32,
     MUL_LO_U32, XOR_B32, MOV_B32, MOV_B64, ADD_U32, LSHL_ADD_U64, MAD_U64_U32, READLANE, WRITELANE, RCP_F32, RSQ_F64, RCP_F64,
-    CVT_F64_F32, CVT_F32_F64, CMP_LT_F64, N_OPS
+    CVT_F64_F32, CVT_F32_F64, CMP_LT_F64, PERM_B32, AND_OR_B32, AND_B32, OR_B32, LSHRREV_B32, BFE_U32, MIN_F32, MUL_F32, ADD_F32, MIN3_F32, MED3_F32, CNDMASK_VCC, LSHL_OR_B32, CVT_UBYTE0, SUB_F32, FMAC_F32, CNDMASK_VCC_E64, CNDMASK_VCC_MIX, MAX_U32, N_OPS
 };
 static const char* kNames[N_OPS] = {
     "v_fma_f32", "v_pk_fma_f32", "v_fma_f64", "v_mul_f64", "v_add_f64", "v_cvt_f32_u32", "v_cvt_f32_u32_sdwa", "v_alignbit_b32", "v_max_f32",
     "v_max3_f32", "v_cndmask_b32", "v_cmp_le_f32", "v_mul_lo_u32", "v_xor_b32", "v_mov_b32", "v_mov_b64", "v_add_u32", "v_lshl_add_u64",
-    "v_mad_u64_u32", "v_readlane_b32", "v_writelane_b32", "v_rcp_f32", "v_rsq_f64", "v_rcp_f64", "v_cvt_f64_f32", "v_cvt_f32_f64", "v_cmp_lt_f64"};
+    "v_mad_u64_u32", "v_readlane_b32", "v_writelane_b32", "v_rcp_f32", "v_rsq_f64", "v_rcp_f64", "v_cvt_f64_f32", "v_cvt_f32_f64", "v_cmp_lt_f64",
+    "v_perm_b32", "v_and_or_b32", "v_and_b32", "v_or_b32", "v_lshrrev_b32", "v_bfe_u32", "v_min_f32", "v_mul_f32", "v_add_f32", "v_min3_f32", "v_med3_f32",
+    "v_cndmask_b32_vcc", "v_lshl_or_b32", "v_cvt_f32_ubyte0", "v_sub_f32", "v_fmac_f32", "v_cndmask_b32_e64_vcc", "v_cndmask_b32_vcc+v_fma_f32 (pair)", "v_max_u32"};
 
 // one instruction of kind OP on accumulator `a` (32-bit) / `d` (64-bit); x, y, xd, yd are loop-invariant operands
 #define ONE(OP, a, d)                                                                                                  \
@@ -64,6 +66,25 @@ static const char* kNames[N_OPS] = {
         else if (OP == CVT_F64_F32) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d) : "v"(a));                           \
         else if (OP == CVT_F32_F64) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a) : "v"(d));                           \
         else if (OP == CMP_LT_F64) asm volatile("v_cmp_lt_f64 vcc, %0, %1" : : "v"(d), "v"(xd) : "vcc");               \
+        else if (OP == PERM_B32) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));                 \
+        else if (OP == AND_OR_B32) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));             \
+        else if (OP == AND_B32) asm volatile("v_and_b32 %0, %1, %0" : "+v"(a) : "v"(x));                               \
+        else if (OP == OR_B32) asm volatile("v_or_b32 %0, %1, %0" : "+v"(a) : "v"(x));                                 \
+        else if (OP == LSHRREV_B32) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(a));                                 \
+        else if (OP == BFE_U32) asm volatile("v_bfe_u32 %0, %0, 3, 16" : "+v"(a));                                     \
+        else if (OP == MIN_F32) asm volatile("v_min_f32 %0, %1, %0" : "+v"(a) : "v"(x));                               \
+        else if (OP == MUL_F32) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a) : "v"(x));                               \
+        else if (OP == ADD_F32) asm volatile("v_add_f32 %0, %1, %0" : "+v"(a) : "v"(x));                               \
+        else if (OP == MIN3_F32) asm volatile("v_min3_f32 %0, %1, %2, %0" : "+v"(a) : "v"(x), "v"(y));                 \
+        else if (OP == MED3_F32) asm volatile("v_med3_f32 %0, %1, %2, %0" : "+v"(a) : "v"(x), "v"(y));                 \
+        else if (OP == CNDMASK_VCC) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a) : "v"(x) : );               \
+        else if (OP == LSHL_OR_B32) asm volatile("v_lshl_or_b32 %0, %0, 3, %1" : "+v"(a) : "v"(x));                    \
+        else if (OP == CVT_UBYTE0) asm volatile("v_cvt_f32_ubyte0 %0, %0" : "+v"(a));                                  \
+        else if (OP == SUB_F32) asm volatile("v_sub_f32 %0, %1, %0" : "+v"(a) : "v"(x));                               \
+        else if (OP == FMAC_F32) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a) : "v"(x), "v"(y));                     \
+        else if (OP == CNDMASK_VCC_E64) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a) : "v"(x));          \
+        else if (OP == CNDMASK_VCC_MIX) asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n v_fma_f32 %2, %1, %1, %2" : "+v"(a), "+v"(b2) : "v"(x)); \
+        else if (OP == MAX_U32) asm volatile("v_max_u32 %0, %1, %0" : "+v"(a) : "v"(x));                               \
     } while (0)
 
 template <int OP>
@@ -72,6 +93,7 @@ __global__ __launch_bounds__(1024) void k_issue(unsigned long long* cycles, floa
     float a[16];
     double d[16];
     const float x = seed + 1.0f, y = seed * 0.5f + 0.25f;
+    float b2 = seed;
     const double xd = (double)seed + 1.0, yd = (double)seed * 0.5 + 0.25;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -79,7 +101,7 @@ __global__ __launch_bounds__(1024) void k_issue(unsigned long long* cycles, floa
         d[i] = (double)seed + (double)(threadIdx.x * 3 + i);
     }
     if (threadIdx.x == 1023) lds[0] = 1;
-    asm volatile("s_mov_b64 s[22:23], 0x5555" : : : "s22", "s23"); // the lane mask v_cndmask selects by
+    asm volatile("s_mov_b64 s[22:23], 0x5555\n s_mov_b64 vcc, 0x3333" : : : "s22", "s23", "vcc"); // the lane masks v_cndmask selects by
     __syncthreads();
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < ITER; ++it) {
@@ -93,6 +115,7 @@ __global__ __launch_bounds__(1024) void k_issue(unsigned long long* cycles, floa
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += a[i] + (float)d[i];
+    s += b2;
     if (s == 1.2345f) sink[0] = s;
     if ((threadIdx.x & 63) == 0) cycles[(size_t)blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;
 }
