@@ -82,6 +82,7 @@ struct PrtScene {
     std::vector<DMaterial> mats;
     std::vector<DTexture> texs;
     std::vector<double> texels_lin; // GetPixel() of every texel (Texture.cpp:50-65)
+    size_t n_texel_reals = 0;       // reals of the footprint array resident on the device (16 per texel)
     prt::LightTree lights;
     prt::BuiltBVH bvh;
     std::vector<uint64_t> mesh_first; // mesh structure, kept for prt_scene_update_vertices
@@ -493,8 +494,36 @@ static int upload_impl(PrtScene* s, int device) {
         if ((rc = s->up(ds, &d.shade))) return rc;
     }
     if ((rc = s->up(s->mats, &d.materials))) return rc;
-    if ((rc = s->up(s->texs, &d.textures))) return rc;
-    if ((rc = s->up(s->texels_lin, &d.texels_lin))) return rc;
+    {
+        // textures go up as bilinear footprints (prt_device.h, tex_value): per cell (x0, y0) the four taps of a lookup, 16 reals
+        std::vector<DTexture> qt(s->texs);
+        std::vector<double> quads;
+        try {
+            size_t cells = 0;
+            for (const DTexture& t : s->texs) cells += t.has_data ? (size_t)t.width * t.height : 0;
+            quads.assign(cells * 16, 0.0);
+        } catch (const std::bad_alloc&) {
+            return fail(PRT_E_OOM, "prt_scene_upload: out of host memory for the texture footprints");
+        }
+        size_t at = 0;
+        for (size_t i = 0; i < s->texs.size(); ++i) {
+            const DTexture& t = s->texs[i];
+            qt[i].offset = at;
+            if (!t.has_data) continue;
+            const double* px = s->texels_lin.data() + t.offset;
+            for (int y0 = 0; y0 < t.height; ++y0)
+                for (int x0 = 0; x0 < t.width; ++x0) {
+                    const int x1 = std::min(x0 + 1, t.width - 1), y1 = std::min(y0 + 1, t.height - 1); // Texture.cpp:35-36
+                    double* o = quads.data() + at;
+                    const int tap[4][2] = {{x0, y0}, {x1, y0}, {x0, y1}, {x1, y1}};
+                    for (int k = 0; k < 4; ++k) std::memcpy(o + 3 * k, px + ((size_t)tap[k][1] * t.width + tap[k][0]) * 3, 24);
+                    at += 16;
+                }
+        }
+        s->n_texel_reals = quads.size();
+        if ((rc = s->up(qt, &d.textures))) return rc;
+        if ((rc = s->up(quads, &d.texels_lin))) return rc;
+    }
     if ((rc = s->up(s->lights.nodes, &d.light_nodes))) return rc;
     if ((rc = s->up(s->lights.tris, &d.light_tris))) return rc;
     d.light_root = s->lights.root;
@@ -641,11 +670,11 @@ static int ensure_f32_impl(PrtScene* s) {
     s->allocs.push_back(t);
     PRT_HIP(hipMalloc(&sh, std::max<size_t>(n * sizeof(DTriShadeT<float>), 256)));
     s->allocs.push_back(sh);
-    PRT_HIP(hipMalloc(&tx, std::max<size_t>(s->texels_lin.size() * sizeof(float), 256)));
+    PRT_HIP(hipMalloc(&tx, std::max<size_t>(s->n_texel_reals * sizeof(float), 256)));
     s->allocs.push_back(tx);
     prt32::launch_convert_tris(d.tris, d.tri_stride, (uint32_t)n, t, stride, nullptr);
     prt32::launch_convert_shade(d.shade, (uint32_t)n, static_cast<DTriShadeT<float>*>(sh), nullptr);
-    prt32::launch_convert_reals(d.texels_lin, s->texels_lin.size(), static_cast<float*>(tx), nullptr);
+    prt32::launch_convert_reals(d.texels_lin, s->n_texel_reals, static_cast<float*>(tx), nullptr);
     PRT_HIP(hipGetLastError());
     std::vector<DMaterialT<float>> mats(s->mats.size());
     for (size_t i = 0; i < mats.size(); ++i) {

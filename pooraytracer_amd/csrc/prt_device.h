@@ -657,10 +657,11 @@ PRT_DEV int wave_count(bool p) { return __popcll(__ballot(p)); }
 // GetPixel (Texture.cpp:50-65).  The per-texel work of the reference — colorScale * byte, then
 // SRGBToLinear for >= 3 channels — is applied once on the host (same std::pow, same doubles) and the
 // device reads the linearised texel as three doubles: 2 loads per tap instead of 6.
-PRT_DEV d3 tex_pixel(const DScene& S, const DTexture& tx, int x, int y) {
-    const real* p = S.texels_lin + tx.offset + (size_t)(y * tx.width + x) * 3;
-    return mk3(p[0], p[1], p[2]);
-}
+// In HBM the texture is stored as its BILINEAR FOOTPRINTS: record (x0, y0) holds the four taps Value() blends for a lookup
+// that lands in that cell — (x0,y0), (x1,y0), (x0,y1), (x1,y1) with x1 = min(x0+1, W-1), y1 = min(y0+1, H-1) — as 12
+// reals padded to 16: one 128-byte line per lookup (two fp32 records per line) instead of the two to four lines the four
+// taps of a row-major texel array touch.  5.3x the bytes of the texel array; only the lines a frame touches matter.
+#define PRT_TEX_QUAD_REALS 16
 PRT_DEV d3 tex_value(const DScene& S, int ti, real u, real v) {
     const DTexture tx = S.textures[ti];
     if (!tx.has_data) return mk3(RL(0.), RL(1.), RL(1.));
@@ -669,10 +670,11 @@ PRT_DEV d3 tex_value(const DScene& S, int ti, real u, real v) {
     real x = u * (tx.width - RL(1.));
     real y = (RL(1.) - v) * (tx.height - RL(1.));
     int x0 = (int)x, y0 = (int)y;
-    int x1 = min(x0 + 1, tx.width - 1), y1 = min(y0 + 1, tx.height - 1);
     real fx = x - x0, fy = y - y0;
-    d3 c00 = tex_pixel(S, tx, x0, y0), c10 = tex_pixel(S, tx, x1, y0);
-    d3 c01 = tex_pixel(S, tx, x0, y1), c11 = tex_pixel(S, tx, x1, y1);
+    const real4* q = reinterpret_cast<const real4*>(S.texels_lin + tx.offset + (size_t)(y0 * tx.width + x0) * PRT_TEX_QUAD_REALS);
+    const real4 q0 = q[0], q1 = q[1], q2 = q[2];
+    d3 c00 = mk3(q0.x, q0.y, q0.z), c10 = mk3(q0.w, q1.x, q1.y);
+    d3 c01 = mk3(q1.z, q1.w, q2.x), c11 = mk3(q2.y, q2.z, q2.w);
     d3 c0 = c00 * (1 - fx) + c10 * fx;
     d3 c1 = c01 * (1 - fx) + c11 * fx;
     return c0 * (1 - fy) + c1 * fy;

@@ -8,7 +8,7 @@
 //   DTriShade[n_tris]   96 B  fp64 shading record in the same order (tangent, texcoords, material)
 //   DMaterial[n_mat]          material table (Material.h parameters)
 //   DLightNode/DLightTri      the reference's area-CDF light tree (BVH.cpp:86-100), exact fp64 areas
-//   texels_lin / DTexture     per-texel GetPixel() result (3 doubles, sRGB->linear applied on the host) + descriptors
+//   texels_lin / DTexture     per texel cell the four bilinear taps (GetPixel() results, sRGB->linear applied on the host; 16 reals) + descriptors
 //
 // Precision: the records that carry real numbers are templates over the scalar type R.  `double` is the reference's
 // arithmetic (glm::dvec3 everywhere) and what every host-side builder fills in; `float` is the layout of the fp32 fast
@@ -114,16 +114,19 @@ typedef DTriT<prt_real> DTri;
 static_assert(sizeof(DTriT<double>) == 128, "DTri must be 128 bytes");
 #endif
 
+#ifndef PRT_SHADE_PADDED
+#define PRT_SHADE_PADDED 0 // 1: shading records one per 128-byte line instead of packed at 96 / 48 bytes — measured: cornell +2.3 %, bathroom2 +1.2 % slower
+#endif
 template <typename R>
-struct alignas(4 * sizeof(R)) DTriShadeT {
+struct alignas(PRT_SHADE_PADDED ? 16 * sizeof(R) : 4 * sizeof(R)) DTriShadeT {
     R tangent[3]; // Triangle.cpp:31-46
     R uv0[2], uv1[2], uv2[2];
     int32_t material;
     int32_t prim;      // index in PrtSceneDesc order
-    R pad[sizeof(R) == 8 ? 2 : 1];
+    R pad[PRT_SHADE_PADDED ? (sizeof(R) == 8 ? 6 : 5) : (sizeof(R) == 8 ? 2 : 1)];
 };
 typedef DTriShadeT<prt_real> DTriShade;
-static_assert(sizeof(DTriShadeT<double>) == 96 && sizeof(DTriShadeT<float>) == 48, "DTriShade must be 96 / 48 bytes");
+static_assert(sizeof(DTriShadeT<double>) == (PRT_SHADE_PADDED ? 128 : 96) && sizeof(DTriShadeT<float>) == (PRT_SHADE_PADDED ? 64 : 48), "DTriShade must be 96 / 48 (128 / 64) bytes");
 
 template <typename R>
 struct alignas(16) DMaterialT {
@@ -142,7 +145,7 @@ static_assert(sizeof(DMaterialT<double>) == 192 && sizeof(DMaterialT<float>) % 1
 
 struct DTexture {
     int32_t width, height, channels, has_data;
-    uint64_t offset; // index of the texture's first double in texels_lin
+    uint64_t offset; // index of the texture's first real in texels_lin
 };
 
 template <typename R>
@@ -172,7 +175,7 @@ struct DSceneT {
     const DTriShadeT<R>* shade;
     const DMaterialT<R>* materials;
     const DTexture* textures;
-    const R* texels_lin; // linearised texels, 3 reals each: GetPixel() of Texture.cpp:50-65 evaluated on the host
+    const R* texels_lin; // linearised texels (GetPixel() of Texture.cpp:50-65 evaluated on the host) as bilinear footprints: 16 reals per cell (prt_device.h, tex_value)
     const DLightNodeT<R>* light_nodes;
     const DLightTriT<R>* light_tris;
     int32_t light_root; // ref into light tree; valid iff n_lights > 0
