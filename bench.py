@@ -626,13 +626,22 @@ def main():
                      x.get("f32", {}).get("parity_check", {}).get("ok", True) for x in checks)
             out["checks_ok"] = ok
             # every workload's number in a few hundred bytes, ahead of the detailed entries (a truncated log still carries them)
-            out["workloads_summary"] = [
+            summary = [
                 {"name": x["workload"], "mrays_per_s": x["value"], "ms_per_step": x["ms_per_step"], "mpaths_per_s": x.get("mpaths_per_s"),
                  "bound": x["roofline"].get("bound"), "frac": x["roofline"].get("frac"),
                  "parity_ok": x.get("parity_check", {}).get("ok"), "bad_px": x.get("parity_check", {}).get("bad_px")}
                 for x in checks]
+            # key order of the line: scalars, config, the summary, then the detailed objects
+            head = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                        "vs_baseline", "dtype", "data", "config")}
+            head["checks_ok"] = ok
+            head["workloads_summary"] = summary
+            head.update({k: v for k, v in out.items() if k not in head})
+            out = head
             if extras:
                 out["workloads"] = extras
+            # ... and once more as the LAST key: whichever end of the line a log keeps, the numbers are in it
+            out["workloads_summary_tail"] = out["workloads_summary"]
             print(json.dumps(out), flush=True)
     if in_group:
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if rehearsal else "cuda")
