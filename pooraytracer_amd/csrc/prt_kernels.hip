@@ -92,6 +92,9 @@ __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
+#ifndef PRT_EARLY_NORMAL
+#define PRT_EARLY_NORMAL 0 // measured: cornell +-0, bathroom2 -0.2 %, veach-mis +1.1 % slower (its plates never use the normal)
+#endif
 #ifndef PRT_ROUND_PRIO
 #define PRT_ROUND_PRIO 0 // s_setprio during traversal rounds: measured cornell -0.9 %, bathroom2 +1.0 %, veach-mis +0.2 %
 #endif
@@ -481,7 +484,16 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
                     TRACE_VERTEX(-1);
                     end_sample = true;
                 } else {
+#if PRT_EARLY_NORMAL
+                    // The triangle's normal (needed for next-event estimation) is requested TOGETHER with the material index, not
+                    // after the emission test that depends on it: one memory round trip instead of two in a pass whose time
+                    // is mostly such round trips (the pass side is 33-61 % of a frame at 20-25 % of its vector instructions).
+                    d3 gn = ld3(tri_at<PAD>(S, (uint32_t)tr.hit.tri)->n);
+#endif
                     const DMaterial& m = MATERIAL(S.shade[tr.hit.tri].material);
+#if PRT_EARLY_NORMAL
+                    asm volatile("" : "+v"(gn.x), "+v"(gn.y), "+v"(gn.z)); // keeps the request up here (the index above is waited for anyway)
+#endif
                     TRACE_VERTEX(S.shade[tr.hit.tri].prim);
                     if (m.has_emission) {
                         // Camera.cpp:129-132; via a bounce only after SkipLightSampling materials (:191-195)
@@ -494,7 +506,9 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
                         do_scatter = true;
                         if (P.sample_lights && S.n_lights > 0 && !m.skip_light_sampling) {
                             // next-event estimation, Camera.cpp:137-155: pick the light point now (4 draws)
+#if !PRT_EARLY_NORMAL
                             const d3 gn = ld3(tri_at<PAD>(S, (uint32_t)sh_tri)->n);
+#endif
                             const d3 fn = dot(rd, gn) < RL(0.) ? gn : -gn;
                             const LightPick lp = sample_lights<LLDS>(S, tr.o, rng, lds_lights, P.light_lds, lds_ltris, P.ltri_lds);
                             real dist;
