@@ -1320,12 +1320,15 @@ int prt_render_multi(PrtScene* const* scenes, int n, const PrtCamera* cam, const
         const int rc = prt_render_device(s, cam, &pr, nullptr, s->multi_fb, 0, nullptr);
         if (rc != PRT_OK) return rc;
     }
+    // test hook: a single scene goes through the RCCL branch as well (a communicator of one rank) — the most of that branch
+    // a one-GPU box can execute: library, communicator, the grouped reduce on the device buffer, the stream order
+    const bool force_rccl = n == 1 && std::getenv("PRT_TEST_FORCE_RCCL") && std::atoi(std::getenv("PRT_TEST_FORCE_RCCL"));
     if (n > 1 && all_same) {
         // tile shares of one device (replicas; a rehearsal of the multi-GPU path on one GPU): summed where they are
         PRT_HIP(hipSetDevice(devs[0]));
         for (int r = 1; r < n; ++r) prt::launch_add_f32(scenes[0]->multi_fb, scenes[r]->multi_fb, npx, nullptr);
         PRT_HIP(hipGetLastError());
-    } else if (n > 1) {
+    } else if (n > 1 || force_rccl) {
         // ONE collective: reduce(sum) of the fp32 framebuffers to the first device over RCCL (xGMI between the GPUs of a
         // node).  Tiles are disjoint, so every element is x + 0 + ... + 0: the result is the single-GPU image bit for bit.
         CommSet* cs = nullptr;

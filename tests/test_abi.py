@@ -83,6 +83,13 @@ def test_compute_fails_loudly_without_upload(prt_lib):
     assert e.value.code == _abi.PRT_E_NO_DEVICE
     with pytest.raises(api.PrtError):
         sc.render(spp=1)
+    # the round-3 entry points refuse the same way: no device, no CPU path behind them
+    with pytest.raises(api.PrtError) as e:
+        sc.render_samples([[1, 1]], spp=2)
+    assert e.value.code == _abi.PRT_E_NO_DEVICE
+    with pytest.raises(api.PrtError) as e:
+        api.render_multi([sc, api.Scene(scenes.tiny_scene())], spp=1)
+    assert e.value.code == _abi.PRT_E_NO_DEVICE
 
 
 def test_scene_create_rejects_bad_input(prt_lib):

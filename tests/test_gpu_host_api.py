@@ -76,6 +76,14 @@ def test_render_multi_on_one_device_and_over_rccl(gpu):
         api.render_multi([reps[0], reps[0]], spp=2, max_depth=2)
     with pytest.raises(api.PrtError):
         api.render_multi([reps[0], api.Scene(data)], spp=2, max_depth=2)
+    # a communicator of ONE rank: everything of the RCCL branch a one-GPU box can run (ncclCommInitAll, grouped ncclReduce on
+    # the device framebuffer, stream order, the copy back)
+    os.environ["PRT_TEST_FORCE_RCCL"] = "1"
+    try:
+        for _ in range(2):
+            assert np.array_equal(api.render_multi(reps[:1], spp=6, max_depth=6, seed=3), want)
+    finally:
+        del os.environ["PRT_TEST_FORCE_RCCL"]
     ndev = api.device_count()
     if ndev >= 2:
         n = min(ndev, 4)
