@@ -848,3 +848,26 @@ def test_headline_rows_equal_the_oracle_on_every_pixel(gpu):
     rel = np.abs(img[y0:y1] - ref[y0:y1]) / np.maximum(1.0, np.abs(ref[y0:y1]))
     assert (rel <= 1e-9).all(), (int((rel > 1e-9).any(-1).sum()), float(rel.max()))
     assert rel.max() <= 1e-12   # observed 9e-15: summation order and last-bit arithmetic only
+
+
+def test_the_one_pixel_of_the_headline_frame_that_differs_is_the_zero_draw(gpu):
+    """Whole-frame parity of the headline configuration (tools/full_frame_parity.py, profiles/r03_full_frame_parity.json): ONE
+    pixel of 1,048,576 is beyond 1e-9 — (296, 161), through sample 465 alone.  It is a true knife edge with a known trigger:
+    the sixth number of that sample's stream is exactly 0 (probability 2^-31 per draw), it is the first draw of the cosine
+    sample at the camera vertex, so the concentric map lands ON the unit circle (r = -1) and z = sqrt(max(0, 1 - x^2 - y^2))
+    is 0 or ~1e-8 depending on the last bit of cos^2 + sin^2 — the reference's `while (wi.z <= 0)` (Material.h:111-116)
+    redraws on one side of that bit and not on the other (glibc's sin / cos there, the fdlibm kernels here).  Every other
+    sample of the pixel agrees to 1e-9, and the signatures agree up to that vertex."""
+    data = scenes.cornell_box()
+    cam = data.camera
+    sc = api.Scene(data).upload(gpu)
+    orc = oracle.Oracle(data)
+    px = [[296, 161]]
+    g, gt = sc.render_samples(px, spp=500, max_depth=20, seed=1, trace=True)
+    o, ot = orc.render_samples(px, spp=500, max_depth=20, seed=1, trace=True)
+    rel = (np.abs(g[0] - o[0]) / np.maximum(1.0, np.abs(o[0]))).max(-1)
+    differing = np.nonzero(rel > 1e-9)[0].tolist()
+    assert differing in ([465], []), differing     # ([]: should both sides ever round that bit the same way)
+    stream = oracle.rng_stream(1, 161 * cam.width + 296, 465, 8)
+    assert stream[5] == 0.0                        # draws 0-3 light pick, 4 roulette, 5-6 the cosine sample: u.y = 0 -> r = -1
+    assert gt[0, 465, 1] == ot[0, 465, 1] and gt[0, 465, 2] == ot[0, 465, 2]   # same camera vertex, same decisions there
