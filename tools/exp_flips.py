@@ -9,7 +9,7 @@ import oracle
 
 name = os.environ.get("FL_SCENE", "cornell")
 fn, kw, spp, depth = {"cornell": (scenes.cornell_box, {}, 500, 20), "cornell-ct": (scenes.cornell_box, {"ball_cooktorrance_alpha": 0.1}, 100, 10),
-                      "veach": (scenes.veach_mis, {}, 300, 100), "bathroom": (scenes.bathroom, {}, 100, 50)}[name]
+                      "veach": (scenes.veach_mis, {}, 300, 100), "bathroom": (scenes.bathroom, {}, 100, 50), "bathroom500": (scenes.bathroom, {}, 500, 50)}[name]
 rows = int(os.environ.get("FL_ROWS", "112"))
 data = fn(**kw)
 cam = data.camera
@@ -42,6 +42,8 @@ for (jj, i) in bad[:40]:
         print(f"      gpu    n={a[0]} {[(int(a[1+2*v]), int(a[2+2*v])) for v in range(a[0])]}")
         print(f"      oracle n={b[0]} {[(int(b[1+2*v]), int(b[2+2*v])) for v in range(b[0])]}")
         print(f"      first differing vertex: {first}", flush=True)
+        st = oracle.rng_stream(1, j * cam.width + int(i), int(s), 256)
+        print(f"      draws of exactly 0 in the sample's first 256 numbers: {np.nonzero(st == 0.0)[0].tolist()}", flush=True)
         out.append(dict(scene=name, pixel=[int(i), j], sample=int(s), gpu=gs[0, s].tolist(), oracle=os_[0, s].tolist(),
                         gpu_trace=a[:1 + 2 * a[0]].tolist(), oracle_trace=b[:1 + 2 * b[0]].tolist(), first_diff=first))
 json.dump(out, open(f"gpurun_out/flips_{name}.json", "w"))

@@ -9,10 +9,15 @@ from pooraytracer_amd import api, scenes
 import oracle
 
 out = {}
-for name, fn, kw, spp, depth in (("cornell-box spp 500 depth 20", scenes.cornell_box, {}, 500, 20),
-                                 ("veach-mis spp 300 depth 100", scenes.veach_mis, {}, 300, 100),
-                                 ("bathroom2 spp 100 depth 50", scenes.bathroom, {}, 100, 50),
-                                 ("cornell-ct spp 100 depth 10", scenes.cornell_box, {"ball_cooktorrance_alpha": 0.1}, 100, 10)):
+CONFIGS = [("cornell-box spp 500 depth 20", scenes.cornell_box, {}, 500, 20),
+           ("veach-mis spp 300 depth 100", scenes.veach_mis, {}, 300, 100),
+           ("bathroom2 spp 100 depth 50", scenes.bathroom, {}, 100, 50),
+           ("cornell-ct spp 100 depth 10", scenes.cornell_box, {"ball_cooktorrance_alpha": 0.1}, 100, 10)]
+if os.environ.get("FF_FULL") == "1":  # the remaining BASELINE configurations at their full sample counts (minutes of oracle time each)
+    CONFIGS = [("cornell-box spp 10 depth 10 (config 1)", scenes.cornell_box, {}, 10, 10),
+               ("veach-mis spp 3000 depth 100 (config 3)", scenes.veach_mis, {}, 3000, 100),
+               ("bathroom2 spp 500 depth 50 (config 5's frame)", scenes.bathroom, {}, 500, 50)]
+for name, fn, kw, spp, depth in CONFIGS:
     data = fn(**kw)
     cam = data.camera
     sc = api.Scene(data).upload(0)
@@ -29,4 +34,4 @@ for name, fn, kw, spp, depth in (("cornell-box spp 500 depth 20", scenes.cornell
                  "width": cam.width, "height": cam.height}
     print(name, out[name], flush=True)
     del sc
-json.dump(out, open("gpurun_out/r03_full_frame_parity.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r03_full_frame_parity%s.json" % ("_full_spp" if os.environ.get("FF_FULL") == "1" else ""), "w"), indent=1)
