@@ -69,6 +69,14 @@ constexpr int render_waves(int feat) {
          : feat == PRT_FEAT_PHONG ? PRT_RENDER_WAVES_PHONG
          : PRT_RENDER_WAVES;
 }
+// Paths a wave may keep aside in LDS to trade lanes' finished rays for ones of the kind the pass serves (k_render, "lane pool"):
+// only where LDS is to spare — the fp64 permutations that run two blocks per CU.  MEASURED AND REJECTED (round 3, DESIGN.md §4:
+// parity green, veach-mis 8.7 % and cornell-ct 3 % slower with 24 paths per wave — the exchange costs what the skipped
+// block saves), hence 0; kept as a build option because it is the regrouping experiment the design notes refer to.
+#ifndef PRT_POOL
+#define PRT_POOL 0
+#endif
+constexpr int render_pool(int feat) { return (!PRT_F32_TU && PRT_POOL > 0 && render_waves(feat) == 2) ? PRT_POOL : 0; }
 // The stepping loop of a wave runs while MORE than this many lanes are still traversing; below it the
 // finished lanes are handed new rays (K1) / shaded and re-armed (K3).
 #ifndef PRT_K1_KEEP
@@ -247,18 +255,20 @@ PRT_DEV ShadeCtx make_ctx(const DScene& S, d3 rd, real alpha, real beta, int32_t
 }
 
 // A real number parked in / fetched from a lane's LDS column (`base` = the lane's slot of word 0, words PRT_BLOCK apart)
+template <int PARK_STRIDE>
 PRT_DEV void park_real(uint32_t* base, int word, real v) {
     if (PRT_F32) {
-        base[word * PRT_BLOCK] = __float_as_uint((float)v);
+        base[word * PARK_STRIDE] = __float_as_uint((float)v);
     } else {
         const unsigned long long b = (unsigned long long)__double_as_longlong((double)v);
-        base[word * PRT_BLOCK] = (uint32_t)b;
-        base[(word + 1) * PRT_BLOCK] = (uint32_t)(b >> 32);
+        base[word * PARK_STRIDE] = (uint32_t)b;
+        base[(word + 1) * PARK_STRIDE] = (uint32_t)(b >> 32);
     }
 }
+template <int PARK_STRIDE>
 PRT_DEV real unpark_real(const uint32_t* base, int word) {
-    if (PRT_F32) return (real)__uint_as_float(base[word * PRT_BLOCK]);
-    return (real)__longlong_as_double((long long)(((unsigned long long)base[(word + 1) * PRT_BLOCK] << 32) | base[word * PRT_BLOCK]));
+    if (PRT_F32) return (real)__uint_as_float(base[word * PARK_STRIDE]);
+    return (real)__longlong_as_double((long long)(((unsigned long long)base[(word + 1) * PARK_STRIDE] << 32) | base[word * PARK_STRIDE]));
 }
 #define PRT_RW ((int)(sizeof(real) / 4)) // dwords per real
 // a lane's parked camera ray and primary hit: t | triangle | direction[3] | (textured permutations) alpha, beta
@@ -302,8 +312,14 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
     __shared__ uint32_t s_qoff[PRT_BLOCK / 64];
     __shared__ unsigned long long s_rays[PRT_BLOCK / 64];
     __shared__ real s_center[4]; // Camera::center, the origin of every camera ray
-    __shared__ uint32_t s_park[PARK_WORDS(FEAT)][PRT_BLOCK]; // per lane: the work item's camera ray and its hit (ST_PRIMARY), read once per sample
-    uint32_t* const park = &s_park[0][threadIdx.x];
+    constexpr int POOL = render_pool(FEAT);              // paths a wave may keep aside (lane pool, below)
+    constexpr int NPARK = PRT_BLOCK + (PRT_BLOCK / 64) * POOL; // one parked camera hit per path in flight: the lanes' and the pool's
+    constexpr int POOL_WORDS = 17 * PRT_RW + 11 + ((FEAT & PRT_FEAT_TEX) ? 2 * PRT_RW : 0); // a path between two traversals, see the exchange below
+    __shared__ uint32_t s_park[PARK_WORDS(FEAT)][NPARK]; // per path: the work item's camera ray and its hit (ST_PRIMARY), read once per sample
+    __shared__ uint32_t s_pool[PRT_BLOCK / 64][POOL ? POOL_WORDS : 1][POOL ? POOL : 1];
+    __shared__ uint16_t s_pidx[PRT_BLOCK / 64][4][POOL ? POOL : 1]; // per wave: slots holding a closest-kind path, a shadow-kind path, free slots, free parking places
+    uint32_t home = threadIdx.x; // where this lane's path parks its camera hit (travels with the path)
+#define park (&s_park[0][home])
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Dynamic LDS, sized by the host: the four waves' traversal stacks (P.stack_depth entries per lane, lane-strided),
     // then the shading tables.  The depth is a launch parameter: what the scene's tree can need, not the builders' bound of
@@ -321,6 +337,10 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
     if (lane == 0) {
         s_qoff[wave] = 0;
         s_rays[wave] = 0ULL;
+    }
+    if (POOL > 0 && lane < POOL) { // wave-private: no barrier needed (a wave's LDS operations complete in order)
+        s_pidx[wave][2][lane] = (uint16_t)lane;
+        s_pidx[wave][3][lane] = (uint16_t)(PRT_BLOCK + wave * POOL + lane);
     }
     if (threadIdx.x < 3) s_center[threadIdx.x] = A.C.center[threadIdx.x];
     if (!LLDS) __syncthreads(); // (the LLDS kernels synchronise below, after staging their tables)
@@ -413,6 +433,8 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
 #if PRT_K3_PROFILE
     unsigned long long prof_[6] = {0, 0, 0, 0, 0, 0}, prof_t_ = __builtin_readcyclecounter();
 #endif
+    int pool_a = 0, pool_b = 0; // lane pool: paths kept aside whose closest-hit / shadow traversal has finished (wave-uniform)
+    bool dry = false;           // a lane of this wave has found every queue empty: no path is put aside any more
     for (;;) {
         if (COUNT) n_refills++;
         PROF_MARK(0); // traversal rounds (and loop control) since the last mark
@@ -420,6 +442,101 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
 #if PRT_PASS_PRIO
         __builtin_amdgcn_s_setprio(PRT_PASS_PRIO);
 #endif
+        if (POOL > 0) {
+            // ---------------- lane pool (north_star: "wavefront-level ballot / compaction for active-ray sorting").  A pass
+            // costs the wave every shading block one of its lanes needs, whatever the number of lanes in it; lanes come out of
+            // closest-hit and shadow traversals in about equal numbers, so each block runs a quarter full.  Here the pass
+            // serves ONE kind: the lanes of the other kind trade their paths — everything a path carries between two
+            // traversals, POOL_WORDS dwords — for paths of the served kind that the wave has put aside in LDS earlier (or, while
+            // work items are left, just put theirs aside and fetch a new item).  Paths never leave the wave: no locks, the
+            // bookkeeping is scalar.  The image cannot change (a path's arithmetic does not depend on the lane that runs it).
+            const bool idle = !tr.active;
+            const bool is_a = idle && (state == ST_CLOSEST || state == ST_CACHED), is_b = idle && state == ST_SHADOW, is_d = idle && state == ST_DONE;
+            const unsigned long long m_a = __ballot(is_a), m_b = __ballot(is_b), m_d = __ballot(is_d);
+            const int n_a = __popcll(m_a), n_b = __popcll(m_b), n_d = __popcll(m_d);
+            dry = dry || n_d != 0;
+            const bool serve_a = n_a + pool_a >= n_b + pool_b;          // the kind with more paths at hand
+            const unsigned long long m_m = serve_a ? m_b : m_a;          // lanes of the other kind
+            const int n_m = serve_a ? n_b : n_a, c_s = serve_a ? pool_a : pool_b, c_m = serve_a ? pool_b : pool_a;
+            const int n_free = POOL - pool_a - pool_b;
+            const int k_swap = n_m < c_s ? n_m : c_s;                     // trade
+            const int k_dep = dry ? 0 : ((n_m - k_swap) < n_free ? (n_m - k_swap) : n_free); // put aside, fetch a new item
+            const int k_wd = n_d < (c_s - k_swap) ? n_d : (c_s - k_swap); // lanes out of work take a path back
+            if (k_swap + k_dep + k_wd > 0) {
+                uint16_t* const st_s = s_pidx[wave][serve_a ? 0 : 1];
+                uint16_t* const st_m = s_pidx[wave][serve_a ? 1 : 0];
+                const bool is_m = serve_a ? is_b : is_a;
+                const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_m, 0u));
+                const int r_d = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_d >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_d, 0u));
+                const bool sw = is_m && r < k_swap, dep = is_m && !sw && r - k_swap < k_dep, wd = is_d && r_d < k_wd;
+                uint32_t slot = 0, new_home = 0;
+                const uint32_t old_home = home;
+                if (sw) slot = st_s[c_s - 1 - r];
+                if (wd) slot = st_s[c_s - k_swap - 1 - r_d];
+                if (dep) {
+                    slot = s_pidx[wave][2][n_free - 1 - (r - k_swap)];
+                    new_home = s_pidx[wave][3][n_free - 1 - (r - k_swap)];
+                }
+                const bool do_load = sw || wd, do_store = sw || dep;
+                if (do_load || do_store) {
+                    uint32_t* const pp = &s_pool[wave][0][slot];
+                    int w = 0;
+                    auto xw = [&](uint32_t& v) { // (a trade reads the slot before it writes it: LDS operations of a lane complete in order)
+                        uint32_t t = v;
+                        if (do_load) t = pp[w * POOL];
+                        if (do_store) pp[w * POOL] = v;
+                        v = t;
+                        ++w;
+                    };
+                    auto xi = [&](int32_t& v) {
+                        uint32_t u = (uint32_t)v;
+                        xw(u);
+                        v = (int32_t)u;
+                    };
+                    auto xr = [&](real& v) {
+                        if (PRT_F32) {
+                            uint32_t u = __float_as_uint((float)v);
+                            xw(u);
+                            v = (real)__uint_as_float(u);
+                        } else {
+                            const unsigned long long b = (unsigned long long)__double_as_longlong((double)v);
+                            uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+                            xw(lo);
+                            xw(hi);
+                            v = (real)__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                        }
+                    };
+                    auto x3 = [&](d3& v) { xr(v.x); xr(v.y); xr(v.z); };
+                    uint32_t w0 = (uint32_t)state | (first ? 8u : 0u) | (prev_skip ? 16u : 0u) | ((uint32_t)depth << 5);
+                    xw(w0);
+                    if (do_load) {
+                        state = (int)(w0 & 7u);
+                        first = (w0 & 8u) != 0;
+                        prev_skip = (w0 & 16u) != 0;
+                        depth = (int)(w0 >> 5);
+                    }
+                    xw(item); xi(s); xi(s_end); xw(pixel); xw(home);
+                    uint32_t r0 = (uint32_t)rng.s, r1 = (uint32_t)(rng.s >> 32);
+                    xw(r0); xw(r1);
+                    rng.s = ((uint64_t)r1 << 32) | r0;
+                    x3(pst_[0]); x3(pst_[1]); x3(tr.o); x3(tr.d); xr(tr.hit.t); xi(tr.hit.tri);
+                    if (FEAT & PRT_FEAT_TEX) { xr(tr.hit.alpha); xr(tr.hit.beta); }
+                    x3(rd); xi(sh_tri); xr(ldist); xi(ltri);
+                }
+                if (sw || dep) st_m[c_m + r] = (uint16_t)slot;
+                if (wd) {
+                    s_pidx[wave][2][n_free + r_d] = (uint16_t)slot;
+                    s_pidx[wave][3][n_free + r_d] = (uint16_t)old_home;
+                }
+                if (dep) { // the lane is free for a new work item (fetched further down in this pass)
+                    home = new_home;
+                    state = ST_FETCH;
+                }
+                const int d_s = -(k_swap + k_wd), d_m = k_swap + k_dep;
+                pool_a += serve_a ? d_s : d_m;
+                pool_b += serve_a ? d_m : d_s;
+            }
+        }
         if (!tr.active) {
             // ---------------- a traversal has just finished on this lane: consume its result
             bool end_sample = false, do_scatter = false;
@@ -465,11 +582,11 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
             if (state == ST_PRIMARY) {
                 // its hit serves every sample of the item (the barycentrics are only ever read for texture coordinates:
                 // untextured permutations keep t and the triangle)
-                park_real(park, PARK_T, tr.hit.t);
-                park[PARK_TRI * PRT_BLOCK] = (uint32_t)tr.hit.tri;
+                park_real<NPARK>(park, PARK_T, tr.hit.t);
+                park[PARK_TRI * NPARK] = (uint32_t)tr.hit.tri;
                 if (FEAT & PRT_FEAT_TEX) {
-                    park_real(park, PARK_AB_AT(FEAT), tr.hit.alpha);
-                    park_real(park, PARK_AB_AT(FEAT) + PRT_RW, tr.hit.beta);
+                    park_real<NPARK>(park, PARK_AB_AT(FEAT), tr.hit.alpha);
+                    park_real<NPARK>(park, PARK_AB_AT(FEAT) + PRT_RW, tr.hit.beta);
                 }
                 state = ST_NEW_SAMPLE; // set up at the bottom of this pass, consumed by the next one
             }
@@ -677,9 +794,9 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
                             tr.o = mk3(q->C.center[0], q->C.center[1], q->C.center[2]);
                             tr.d = ps - tr.o;
                             if (!PARK_DIR_GLOBAL(FEAT)) {
-                                park_real(park, PARK_DIR, tr.d.x);
-                                park_real(park, PARK_DIR + PRT_RW, tr.d.y);
-                                park_real(park, PARK_DIR + 2 * PRT_RW, tr.d.z);
+                                park_real<NPARK>(park, PARK_DIR, tr.d.x);
+                                park_real<NPARK>(park, PARK_DIR + PRT_RW, tr.d.y);
+                                park_real<NPARK>(park, PARK_DIR + 2 * PRT_RW, tr.d.z);
                             }
                             state = ST_PRIMARY;
                         }
@@ -709,17 +826,22 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
                     tr.o = mk3(s_center[0], s_center[1], s_center[2]);
                     if (PARK_DIR_GLOBAL(FEAT)) { // Camera::GetRay again (same expressions as at the fetch: the same bits)
                         const ColdRenderArgs q = cold_args();
+                        if (POOL > 0) { // px, py do not travel with a path
+                            const int W = q->C.width;
+                            py = (int)(pixel / (uint32_t)W);
+                            px = (int)(pixel - (uint32_t)py * (uint32_t)W);
+                        }
                         const d3 ps = mk3(q->C.pixel00[0], q->C.pixel00[1], q->C.pixel00[2]) + (real)px * mk3(q->C.du[0], q->C.du[1], q->C.du[2]) +
                                       (real)py * mk3(q->C.dv[0], q->C.dv[1], q->C.dv[2]);
                         tr.d = ps - tr.o;
                     } else {
-                        tr.d = mk3(unpark_real(park, PARK_DIR), unpark_real(park, PARK_DIR + PRT_RW), unpark_real(park, PARK_DIR + 2 * PRT_RW));
+                        tr.d = mk3(unpark_real<NPARK>(park, PARK_DIR), unpark_real<NPARK>(park, PARK_DIR + PRT_RW), unpark_real<NPARK>(park, PARK_DIR + 2 * PRT_RW));
                     }
-                    tr.hit.t = unpark_real(park, PARK_T);
-                    tr.hit.tri = (int32_t)park[PARK_TRI * PRT_BLOCK];
+                    tr.hit.t = unpark_real<NPARK>(park, PARK_T);
+                    tr.hit.tri = (int32_t)park[PARK_TRI * NPARK];
                     if (FEAT & PRT_FEAT_TEX) {
-                        tr.hit.alpha = unpark_real(park, PARK_AB_AT(FEAT));
-                        tr.hit.beta = unpark_real(park, PARK_AB_AT(FEAT) + PRT_RW);
+                        tr.hit.alpha = unpark_real<NPARK>(park, PARK_AB_AT(FEAT));
+                        tr.hit.beta = unpark_real<NPARK>(park, PARK_AB_AT(FEAT) + PRT_RW);
                     }
                     state = ST_CACHED;
                 }
@@ -761,7 +883,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
             const unsigned long long nc = (unsigned long long)__popcll(__ballot(started == 1)), ns = (unsigned long long)__popcll(__ballot(started == 2));
             if (lane == 0) atomicAdd(&s_rays[wave], nc | (ns << 32));
         }
-        if (__ballot(state != ST_DONE) == 0ULL) break;
+        if (__ballot(state != ST_DONE) == 0ULL && pool_a + pool_b == 0) break; // (paths put aside are taken back by the lanes out of work)
         // Lanes that started a sample from the parked hit have nothing to trace: with enough of them the next pass comes at
         // once (it consumes their hits and hands them real rays) instead of after traversal rounds they would sit out.
         if (wave_count(state == ST_CACHED) >= P.cached_min) continue;
@@ -933,7 +1055,10 @@ int render_permutation(int feat) {
 int render_lds_budget(int feat, int stack_depth) {
     int blocks = render_waves(render_permutation(feat));
     if (PRT_F32_TU && stack_depth <= 32) blocks = PRT_F32_WAVES > 4 && stack_depth <= 24 ? 5 : 4; // fp32: registers allow a fourth wave per SIMD when the stacks do
-    return ((160 * 1024 / blocks - (int)sizeof(uint32_t) * (stack_depth + PARK_WORDS(render_permutation(feat))) * PRT_BLOCK - 256) / 512) * 512; // stacks + parked camera rays
+    const int perm = render_permutation(feat), pool = render_pool(perm) * (PRT_BLOCK / 64);
+    const int pool_words = 17 * PRT_RW + 11 + ((perm & PRT_FEAT_TEX) ? 2 * PRT_RW : 0);
+    const int pool_bytes = pool * (int)sizeof(uint32_t) * (pool_words + PARK_WORDS(perm)) + pool * 8; // paths put aside, their parked camera hits, index stacks
+    return ((160 * 1024 / blocks - (int)sizeof(uint32_t) * (stack_depth + PARK_WORDS(perm)) * PRT_BLOCK - pool_bytes - 256) / 512) * 512; // stacks + parked camera rays
 }
 size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds) {
     return (size_t)light_lds * sizeof(DLightNode) + (size_t)mat_lds * sizeof(DMaterial) + (size_t)ltri_lds * sizeof(DLightTri);

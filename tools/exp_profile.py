@@ -13,5 +13,6 @@ for name, fn, spp, depth in (("cornell", scenes.cornell_box, 64, 20), ("bathroom
     c = sc.counters()
     sec = [c["tri_tests"], c["inner_rounds"], c["leaf_rounds"], c["refills"], c["tri_full"]]
     tot = float(sum(sec))
-    print(name, " | ".join(f"{n} {100 * v / tot:.1f}%" for n, v in zip(("rounds", "consume", "roulette+scatter", "end/fetch/new-sample", "set-up"), sec)), flush=True)
+    print(name, " | ".join(f"{n} {100 * v / tot:.1f}%" for n, v in zip(("rounds", "consume", "roulette+scatter", "end/fetch/new-sample", "set-up"), sec)),
+          f"| total {tot / 1e9:.2f} Gcycles", flush=True)
     del sc
