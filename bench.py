@@ -477,6 +477,25 @@ def time_rays(ctx, name, steps, warmup):
                   "parity_check": {"against": "the fp64 kernel's hits", "hit_miss_flips": flips, "beyond_1e-5": int((rel > 1e-5).sum()),
                                    "rel_t_p999": float(np.quantile(rel, 0.999)) if rel.size else 0.0, "tolerance": "1e-5 for all but 1e-4 of the rays",
                                    "ok": bool(flips + int((rel > 1e-5).sum()) <= 1e-4 * n)}}
+    if data.n_tris >= 1_000_000:
+        # K4: the same batch traced in a locality order (keys + radix sort + K1 through the permutation, all inside the time);
+        # the hits must be the unsorted call's, bit for bit.  An extra: the workload's `value` is the batch as given.
+        d_hs = torch.zeros_like(d_h)
+        sc.trace_closest_device(d_r.data_ptr(), n, d_hs.data_ptr(), sort=True)
+        torch.cuda.synchronize()
+        mss = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sc.trace_closest_device(d_r.data_ptr(), n, d_hs.data_ptr(), sort=True)
+            mss.append(sc.counters()["kernel_ms"])
+        torch.cuda.synchronize()
+        els = time.perf_counter() - t0
+        out["k4_sorted"] = {"note": "prt_trace_closest_sorted_device: keys + radix sort + K1 in locality order, all timed; an extra, not `value`",
+                            "value": round(n * steps / els / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(els / steps * 1e3, 3),
+                            "device_ms": round(sum(mss) / len(mss), 3),
+                            "hits_equal_unsorted": bool(np.array_equal(d_hs.cpu().numpy().view(np.uint64), d_h.cpu().numpy().view(np.uint64))),
+                            "l2_misses_per_ray": {"as_given": 32.2, "sorted": 21.8, "source": "profiles/r03_k4_sorted_pmc.txt (TCC_MISS_sum per launch / 2^24)"}}
+        del d_hs
     if not ctx.args.no_cpu_baseline and data.n_tris <= 200_000:
         import oracle
         orc = oracle.Oracle(data)
@@ -572,10 +591,10 @@ def main():
                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": w["config"], "hit_fraction": w["hit_fraction"], "rays_per_launch": w["rays_per_launch"]},
                "roofline": w["roofline"]}
-        for k in ("cpu_baseline", "parity_check"):
+        for k in ("cpu_baseline", "parity_check", "f32", "k4_sorted"):
             if k in w:
                 out[k] = w[k]
-        ok = out.get("parity_check", {}).get("ok", True)
+        ok = out.get("parity_check", {}).get("ok", True) and out.get("k4_sorted", {}).get("hits_equal_unsorted", True)
         print(json.dumps(out), flush=True)
     else:
         w = time_render(ctx, args.workload, args.steps, args.warmup, spp_override=args.spp)
@@ -623,13 +642,14 @@ def main():
                 out["config5"] = config5
             checks = [w] + extras + ([config5] if config5 else [])
             ok = all(x.get("parity_check", {}).get("ok", True) and x.get("assembled_equals_single_rank", True) and
-                     x.get("f32", {}).get("parity_check", {}).get("ok", True) for x in checks)
+                     x.get("f32", {}).get("parity_check", {}).get("ok", True) and x.get("k4_sorted", {}).get("hits_equal_unsorted", True) for x in checks)
             out["checks_ok"] = ok
             # every workload's number in a few hundred bytes, ahead of the detailed entries (a truncated log still carries them)
             summary = [
                 {"name": x["workload"], "mrays_per_s": x["value"], "ms_per_step": x["ms_per_step"], "mpaths_per_s": x.get("mpaths_per_s"),
                  "bound": x["roofline"].get("bound"), "frac": x["roofline"].get("frac"),
-                 "parity_ok": x.get("parity_check", {}).get("ok"), "bad_px": x.get("parity_check", {}).get("bad_px")}
+                 "parity_ok": x.get("parity_check", {}).get("ok"), "bad_px": x.get("parity_check", {}).get("bad_px"),
+                 **({"k4_sorted_mrays_per_s": x["k4_sorted"]["value"]} if "k4_sorted" in x else {})}
                 for x in checks]
             # key order of the line: scalars, config, the summary, then the detailed objects
             head = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",

@@ -226,6 +226,16 @@ int prt_trace_closest_device(PrtScene* scene, const void* d_rays, size_t n, void
 int prt_trace_closest_device_prec(PrtScene* scene, const void* d_rays, size_t n, void* d_hits,
                                   int count_work, int precision, void* hip_stream);
 
+/* K4 + K1: the same batch traced in a locality order.  A pre-pass sorts (cell of the origin in the scene's box, octant of
+ * the direction) keys on the device and K1 takes the rays in that order, so that the lanes of a wave walk the same part
+ * of the tree — for scenes whose BVH and triangles exceed the caches (several million triangles) and batches of
+ * incoherent rays, where every node visit is otherwise a line of its own from HBM.  hits[i] still answers rays[i], bit
+ * for bit what prt_trace_closest_device_prec returns; the time reported by prt_get_counters covers keys + sort + trace.
+ * Needs 16 bytes of scratch per ray (kept by the scene between calls); n < 2^32.  On cache-resident scenes the sort costs
+ * more than it returns. */
+int prt_trace_closest_sorted_device(PrtScene* scene, const void* d_rays, size_t n, void* d_hits,
+                                    int count_work, int precision, void* hip_stream);
+
 /* NEE point selection for (pixel, sample) keys 0..n-1 of `seed` from given origins (test hook). */
 int prt_sample_lights(PrtScene* scene, const double* origins, size_t n, uint64_t seed,
                       PrtLightSample* out);

@@ -191,6 +191,7 @@ EXPORTS = [
     "prt_trace_closest",
     "prt_trace_closest_device",
     "prt_trace_closest_device_prec",
+    "prt_trace_closest_sorted_device",
     "prt_sample_lights",
     "prt_render",
     "prt_render_device",

@@ -56,6 +56,7 @@ def load():
     L.prt_trace_closest.argtypes = [vp, vp, sz, vp, i32]
     L.prt_trace_closest_device.argtypes = [vp, vp, sz, vp, i32, vp]
     L.prt_trace_closest_device_prec.argtypes = [vp, vp, sz, vp, i32, i32, vp]
+    L.prt_trace_closest_sorted_device.argtypes = [vp, vp, sz, vp, i32, i32, vp]
     L.prt_sample_lights.argtypes = [vp, vp, sz, u64, vp]
     L.prt_render.argtypes = [vp, vp, vp, vp, vp]
     L.prt_render_device.argtypes = [vp, vp, vp, vp, vp, i32, vp]
@@ -144,9 +145,11 @@ class Scene:
         _check(load().prt_trace_closest(self._h, rays.ctypes.data, rays.shape[0], hits.ctypes.data, int(count_work)))
         return hits
 
-    def trace_closest_device(self, d_rays_ptr, n, d_hits_ptr, count_work=False, stream=None, precision=0):
-        """K1 on device buffers; precision = _abi.PRECISION_F64 (default) or PRECISION_F32 (fp32 fast mode)."""
-        _check(load().prt_trace_closest_device_prec(self._h, d_rays_ptr, n, d_hits_ptr, int(count_work), int(precision), stream))
+    def trace_closest_device(self, d_rays_ptr, n, d_hits_ptr, count_work=False, stream=None, precision=0, sort=False):
+        """K1 on device buffers; precision = _abi.PRECISION_F64 (default) or PRECISION_F32 (fp32 fast mode).  sort=True: K4
+        first — the batch is traced in a locality order (same hits, for scenes that do not fit the caches)."""
+        fn = load().prt_trace_closest_sorted_device if sort else load().prt_trace_closest_device_prec
+        _check(fn(self._h, d_rays_ptr, n, d_hits_ptr, int(count_work), int(precision), stream))
 
     def sample_lights(self, origins, seed=1):
         origins = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)

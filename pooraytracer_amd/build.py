@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libprt_hip.so")
-SOURCES = ["prt_api.cpp", "prt_kernels.hip", "prt_kernels_f32.hip", "bvh_build.cpp", "bvh_build_gpu.hip", "scene_setup.cpp"]
+SOURCES = ["prt_api.cpp", "prt_kernels.hip", "prt_kernels_f32.hip", "bvh_build.cpp", "bvh_build_gpu.hip", "ray_sort.hip", "scene_setup.cpp"]
 HEADERS = ["prt_types.h", "prt_device.h", "prt_host.h", os.path.join("..", "..", "include", "prt.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",

@@ -26,7 +26,11 @@ int render_permutation(int feat);
 int render_lds_budget(int feat, int stack_depth);
 size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds);
 void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hits, DCounters* d_ctr, bool count, int n_cu,
-                  hipStream_t st);
+                  hipStream_t st, const uint32_t* d_perm = nullptr);
+// K4 (ray_sort.hip): a permutation of a ray batch in which consecutive rays start close together
+size_t ray_sort_scratch_bytes(size_t n, std::string* err);
+const uint32_t* ray_sort(const PrtRay* d_rays, size_t n, const float grid_origin[3], const float grid_step[3], void* scratch,
+                         size_t scratch_bytes, hipStream_t st, std::string* err);
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,
                    bool count, int feat, unsigned grid, hipStream_t st);
 void launch_finalize(const DCamera& C, const DRenderParams& P, const double* d_partial, double* d64, float* d32,
@@ -52,7 +56,7 @@ int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_dep
 int render_lds_budget(int feat, int stack_depth);
 size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds);
 void launch_trace(const Scene32& S, const PrtRay* d_rays, size_t n, PrtHit* d_hits, DCounters* d_ctr, bool count, int n_cu,
-                  hipStream_t st);
+                  hipStream_t st, const uint32_t* d_perm = nullptr);
 void launch_render(const Scene32& S, const DCameraT<float>& C, const DRenderParamsT<float>& P, double* d_partial,
                    DCounters* d_ctr, bool count, int feat, unsigned grid, hipStream_t st);
 void launch_convert_tris(const void* in, uint32_t in_stride, uint32_t n, void* out, uint32_t out_stride, hipStream_t st);
@@ -124,6 +128,11 @@ struct PrtScene {
         bool counted = false;
         uint64_t samples = 0; // camera samples of the call (render: owned pixels inside the image x spp; the kernel does not count them)
     };
+    // prt_trace_closest_sorted_device: K4's keys, values and the permutation — one scratch area per scene, kept between
+    // calls; a call on another stream first waits for the previous sorted call's end (sort_done)
+    void* d_sort = nullptr;
+    size_t sort_cap = 0;
+    hipEvent_t sort_done = nullptr;
     CallSlot slots[2];
     int cur = 0; // slot of the most recent call (prt_get_counters reads it)
     // Next slot for an asynchronous call on `st`.  A slot may still be in use by a call issued two calls ago on
@@ -158,6 +167,11 @@ struct PrtScene {
         if (multi_fb) (void)hipFree(multi_fb);
         multi_fb = nullptr;
         multi_fb_cap = 0;
+        if (d_sort) (void)hipFree(d_sort);
+        d_sort = nullptr;
+        sort_cap = 0;
+        if (sort_done) (void)hipEventDestroy(sort_done);
+        sort_done = nullptr;
         for (CallSlot& q : slots) {
             if (q.d_ctr) (void)hipFree(q.d_ctr);
             if (q.d_partial) (void)hipFree(q.d_partial);
@@ -785,10 +799,19 @@ int prt_trace_closest_device(PrtScene* s, const void* d_rays, size_t n, void* d_
     return prt_trace_closest_device_prec(s, d_rays, n, d_hits, count_work, PRT_PRECISION_F64, stream);
 }
 
+static int trace_closest_device(PrtScene* s, const void* d_rays, size_t n, void* d_hits, int count_work, int precision, void* stream, bool sorted);
 int prt_trace_closest_device_prec(PrtScene* s, const void* d_rays, size_t n, void* d_hits, int count_work, int precision,
                                   void* stream) {
+    return trace_closest_device(s, d_rays, n, d_hits, count_work, precision, stream, false);
+}
+int prt_trace_closest_sorted_device(PrtScene* s, const void* d_rays, size_t n, void* d_hits, int count_work, int precision,
+                                    void* stream) {
+    return trace_closest_device(s, d_rays, n, d_hits, count_work, precision, stream, true);
+}
+static int trace_closest_device(PrtScene* s, const void* d_rays, size_t n, void* d_hits, int count_work, int precision, void* stream, bool sorted) {
     int rc = require_uploaded(s, "prt_trace_closest_device");
     if (rc) return rc;
+    if (sorted && n > 0xffffffffull) return fail(PRT_E_INVALID, "prt_trace_closest_sorted_device: more than 2^32 - 1 rays in one batch");
     if (n && (!d_rays || !d_hits)) return fail(PRT_E_INVALID, "prt_trace_closest_device: null buffer");
     if (precision != PRT_PRECISION_F64 && precision != PRT_PRECISION_F32) return fail(PRT_E_INVALID, "prt_trace_closest_device: unsupported precision");
     if (precision == PRT_PRECISION_F32 && (rc = ensure_f32(s))) return rc;
@@ -797,16 +820,38 @@ int prt_trace_closest_device_prec(PrtScene* s, const void* d_rays, size_t n, voi
     PrtScene::CallSlot& q = *s->next_slot(st, &we);
     PRT_HIP(we);
     PRT_HIP(hipMemsetAsync(q.d_ctr, 0, sizeof(DCounters), st));
-    PRT_HIP(hipEventRecord(q.ev0, st));
+    const uint32_t* d_perm = nullptr;
+    if (sorted && n > 1) {
+        std::string err;
+        const size_t need = prt::ray_sort_scratch_bytes(n, &err);
+        if (!need) return fail(PRT_E_HIP, err);
+        if (!s->sort_done) PRT_HIP(hipEventCreateWithFlags(&s->sort_done, hipEventDisableTiming));
+        else PRT_HIP(hipStreamWaitEvent(st, s->sort_done, 0)); // the scratch is the previous sorted call's until that call has ended
+        if (s->sort_cap < need) {
+            PRT_HIP(hipEventSynchronize(s->sort_done)); // (never recorded: returns at once)
+            if (s->d_sort) (void)hipFree(s->d_sort);    // hipFree waits for the device
+            s->d_sort = nullptr;
+            s->sort_cap = 0;
+            if (hipMalloc(&s->d_sort, need) != hipSuccess) return fail(PRT_E_OOM, "prt_trace_closest_sorted_device: hipMalloc of the sort scratch failed");
+            s->sort_cap = need;
+        }
+    }
+    PRT_HIP(hipEventRecord(q.ev0, st)); // (the sort is inside the timed region: kernel_ms is keys + sort + trace)
+    if (sorted && n > 1) {
+        std::string err;
+        d_perm = prt::ray_sort(static_cast<const PrtRay*>(d_rays), n, s->d.grid_origin, s->d.grid_step, s->d_sort, s->sort_cap, st, &err);
+        if (!d_perm) return fail(PRT_E_HIP, err);
+    }
     if (precision == PRT_PRECISION_F32)
         prt32::launch_trace(s->d32, static_cast<const PrtRay*>(d_rays), n, static_cast<PrtHit*>(d_hits), q.d_ctr, count_work != 0,
-                            s->n_cu, st);
+                            s->n_cu, st, d_perm);
     else
         prt::launch_trace(s->d, static_cast<const PrtRay*>(d_rays), n, static_cast<PrtHit*>(d_hits), q.d_ctr, count_work != 0,
-                          s->n_cu, st);
+                          s->n_cu, st, d_perm);
     PRT_HIP(hipGetLastError());
     PRT_HIP(hipEventRecord(q.ev1, st));
     PRT_HIP(hipEventRecord(q.done, st));
+    if (d_perm) PRT_HIP(hipEventRecord(s->sort_done, st));
     q.timed = true;
     q.counted = count_work != 0;
     q.samples = 0;

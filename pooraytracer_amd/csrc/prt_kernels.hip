@@ -134,7 +134,8 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 // PRT_K1_KEEP lanes are still traversing.
 template <bool COUNT, bool PAD>
 __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScene S, const PrtRay* __restrict__ rays, size_t n,
-                                                             PrtHit* __restrict__ hits, DCounters* ctr) {
+                                                             PrtHit* __restrict__ hits, DCounters* ctr,
+                                                             const uint32_t* __restrict__ perm) { // K4's order (ray_sort.hip) or null
     __shared__ uint32_t s_stack[PRT_BLOCK / 64][PRT_STACK_DEPTH][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t* stk = &s_stack[wave][0][lane];
@@ -187,10 +188,11 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
                     const unsigned long long below = need & ((1ULL << lane) - 1ULL);
                     const unsigned long long idx = pool_next + (unsigned long long)__popcll(below);
                     if (idx < pool_end) {
-                        const double4* rp = reinterpret_cast<const double4*>(rays + idx);
+                        const size_t ri = perm ? (size_t)perm[idx] : (size_t)idx; // the idx-th ray of the sorted order
+                        const double4* rp = reinterpret_cast<const double4*>(rays + ri);
                         const double4 r0 = rp[0], r1 = rp[1];
                         tr.init(S, mk3((real)r0.x, (real)r0.y, (real)r0.z), mk3((real)r1.x, (real)r1.y, (real)r1.z), (real)r0.w, (real)r1.w); // PrtRay is fp64 at the ABI in either mode
-                        my = (size_t)idx;
+                        my = ri;
                         have = true;
                         nrays++;
                     }
@@ -1098,7 +1100,7 @@ int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_dep
 }
 
 void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hits, DCounters* d_ctr, bool count,
-                  int n_cu, hipStream_t st) {
+                  int n_cu, hipStream_t st, const uint32_t* d_perm) {
     if (n == 0) return;
     size_t want = (n + PRT_BLOCK - 1) / PRT_BLOCK;
     const size_t per_cu = std::max<size_t>(1, (160u * 1024u) / (sizeof(uint32_t) * PRT_STACK_DEPTH * PRT_BLOCK)); // LDS stacks per CU
@@ -1106,7 +1108,7 @@ void launch_trace(const DScene& S, const PrtRay* d_rays, size_t n, PrtHit* d_hit
     const bool pad = S.tri_stride == PRT_TRI_PAD_STRIDE(real) && sizeof(DTri) != PRT_TRI_PAD_STRIDE(real);
     auto k = count ? (pad ? k_trace_closest<true, true> : k_trace_closest<true, false>)
                    : (pad ? k_trace_closest<false, true> : k_trace_closest<false, false>);
-    hipLaunchKernelGGL(k, dim3(grid), dim3(PRT_BLOCK), 0, st, S, d_rays, n, d_hits, d_ctr);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(PRT_BLOCK), 0, st, S, d_rays, n, d_hits, d_ctr, d_perm);
 }
 
 void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, double* d_partial, DCounters* d_ctr,

@@ -167,7 +167,7 @@ def test_cmake_build_produces_the_same_libraries(tmp_path):
     assert "libpooraytracer_host.so" in ldd and "libprt_hip.so" in ldd
 
 
-@pytest.mark.parametrize("flags", [["-DPRT_BVH_WIDTH=2"], ["-DPRT_TRI_FORM=0", "-DPRT_FAST_F64=0"], ["-DPRT_ITEM_QUEUES=1", "-DPRT_K3_PROFILE=1"]])
+@pytest.mark.parametrize("flags", [["-DPRT_BVH_WIDTH=2"], ["-DPRT_TRI_FORM=0", "-DPRT_FAST_F64=0"], ["-DPRT_ITEM_QUEUES=1", "-DPRT_K3_PROFILE=1"], ["-DPRT_POOL=24"]])
 def test_alternative_build_configurations_still_compile(flags):
     """The A/B switches DESIGN.md quotes measurements for (2-wide nodes, the reference's triangle expressions on 128-byte
     records, IEEE sqrt / division in the shading code, one work-item counter, the per-section profile) are compile-time
@@ -178,7 +178,7 @@ def test_alternative_build_configurations_still_compile(flags):
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not installed")
     csrc = os.path.join(ROOT, "pooraytracer_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in ("prt_kernels.hip", "prt_kernels_f32.hip", "bvh_build_gpu.hip", "bvh_build.cpp", "prt_api.cpp")]
+    srcs = [os.path.join(csrc, f) for f in ("prt_kernels.hip", "prt_kernels_f32.hip", "bvh_build_gpu.hip", "ray_sort.hip", "bvh_build.cpp", "prt_api.cpp")]
     r = subprocess.run([hipcc, "-std=c++17", "--offload-arch=gfx950", "-fsyntax-only", "-Wno-unused-function"] + flags + srcs,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]

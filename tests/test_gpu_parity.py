@@ -625,6 +625,34 @@ def test_three_calls_in_flight_on_three_streams(gpu):
         assert np.array_equal(d_h.cpu().numpy(), hits_want)
 
 
+def test_sorted_batch_returns_the_same_hits_in_the_same_places(gpu):
+    """K4 (prt_trace_closest_sorted_device): the batch is traced in a locality order — keys, radix sort, K1 through the
+    permutation — and hits[i] must still answer rays[i], bit for bit what the unsorted call returns: on a cache-resident
+    scene, on a triangle soup, in both precisions, for batches of 0, 1 and an odd number of rays, with origins outside the
+    scene's box and a NaN origin thrown in (it has to come back as a miss, not hang or move other rays' hits)."""
+    import torch
+    for data, n in ((scenes.cornell_box(ball_subdiv=3, width=64, height=64), 200_003), (scenes.triangle_soup(n_tris=300_000, with_light=False), 150_001)):
+        sc = api.Scene(data).upload(0)
+        lo, hi = data.bounds()
+        rays = scenes.random_rays(n, lo - 0.3 * (hi - lo), hi + 0.3 * (hi - lo), seed=9)
+        rays["o"][7] = np.nan
+        d_r = torch.from_numpy(rays.view(np.float64).reshape(-1, 8)).cuda()
+        for prec in (0, 1):
+            for m in (n, 1, 0):
+                a = torch.full((max(m, 1), 4), -7.0, dtype=torch.float64, device="cuda")
+                b = torch.full((max(m, 1), 4), -7.0, dtype=torch.float64, device="cuda")
+                sc.trace_closest_device(d_r.data_ptr(), m, a.data_ptr(), precision=prec)
+                sc.trace_closest_device(d_r.data_ptr(), m, b.data_ptr(), precision=prec, sort=True)
+                torch.cuda.synchronize()
+                assert np.array_equal(a.cpu().numpy().view(np.uint64), b.cpu().numpy().view(np.uint64))
+                if m == n:
+                    c = sc.counters()
+                    assert c["rays_closest"] == n and c["kernel_ms"] > 0
+                    h = a.cpu().numpy().view(_abi.HIT_DTYPE).reshape(-1)
+                    assert h["prim"][7] == -1 and (h["prim"] >= 0).mean() > 0.2
+        del sc
+
+
 def test_counters_report_the_tree_that_is_resident(gpu):
     """prt_get_counters' static fields follow the tree in use, host- or device-built (r1: bvh_nodes was 0 for device builds)."""
     data = scenes.cornell_box(ball_subdiv=2, width=64, height=64)

@@ -45,8 +45,14 @@ if os.environ.get("AB_S4") == "1":
         best = 1e9
         for _ in range(3):
             sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr()); torch.cuda.synchronize(); best = min(best, sc.counters()["kernel_ms"])
+        srt = ""
+        if os.environ.get("AB_SORT") == "1":
+            bs = 1e9
+            for _ in range(3):
+                sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr(), sort=True); torch.cuda.synchronize(); bs = min(bs, sc.counters()["kernel_ms"])
+            srt = f" sorted(K4) {n/bs/1e3:.0f} [{bs:.2f} ms incl. sort]"
         sc.trace_closest_device(d_r.data_ptr(), n, d_h.data_ptr(), count_work=True); torch.cuda.synchronize(); c = sc.counters()
         bi = sc.bvh_info()
-        out.append(f"s4[{'gpu' if dev else 'host'} build {t1:.1f}s nodes {bi['n_nodes']} depth {bi['depth']}] {n/best/1e3:.0f} (n/r {c['node_fetches']/n:.1f} t/r {c['tri_tests']/n:.2f} full/r {c['tri_full']/n:.2f})")
+        out.append(f"s4[{'gpu' if dev else 'host'} build {t1:.1f}s nodes {bi['n_nodes']} depth {bi['depth']}] {n/best/1e3:.0f} (n/r {c['node_fetches']/n:.1f} t/r {c['tri_tests']/n:.2f} full/r {c['tri_full']/n:.2f}){srt}")
         del sc
 print(" | ".join(out), flush=True)
