@@ -24,6 +24,9 @@ template <> struct real4_of<double> { typedef double4 type; };
 template <> struct real4_of<float> { typedef float4 type; };
 typedef real4_of<real>::type real4;
 #define PRT_NOCUR ((int32_t)0x80000000) // Trav::cur sentinel (never a valid leaf ref: n_tris < 2^28)
+#ifndef PRT_PREFETCH_TOP
+#define PRT_PREFETCH_TOP 0 // request the stack's top entry at push time: measured 5-12 % SLOWER on every workload — kept as the A/B switch
+#endif
 #ifndef PRT_DEFER_LEAF
 #define PRT_DEFER_LEAF 0 // speculative leaf deferral: better lane utilisation (node rounds 51%->55%) but 3-5% slower (more triangle tests, heavier leaf rounds) on MI355X
 #endif
@@ -326,6 +329,9 @@ struct Trav {
     int32_t pend; // 0 = none, else a leaf ref reached earlier whose triangles are still to be tested
     int32_t sp;
     bool active;
+#if PRT_PREFETCH_TOP
+    uint32_t pf = 0; // destination of the prefetch of the stack's top entry (never read)
+#endif
 
     PRT_DEV void init(const DScene& S, d3 o_, d3 d_, real tmin_, real tmax_) {
         o = o_;
@@ -465,6 +471,15 @@ struct Trav {
         if (k1 != 0xffffffffu) {
             stk[sp * 64] = r1;
             sp++;
+#if PRT_PREFETCH_TOP
+            // The entry on top of the stack is what this lane visits after the subtree it descends into now: one dword of
+            // it is requested here (result never used), so that the line is on its way — or in L2 — by the time it is popped.
+            {
+                const int32_t rt = (int32_t)r1;
+                const void* a = rt >= 0 ? static_cast<const void*>(S.nodes + rt) : static_cast<const void*>(tri_at<PAD>(S, (~(uint32_t)rt) >> 3));
+                pf = *static_cast<const volatile uint32_t*>(a);
+            }
+#endif
         }
         if (k0 != 0xffffffffu) {
             cur = (int32_t)r0;

@@ -208,6 +208,9 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
             tr.template round<COUNT>(S, stk, wc, PRT_LEAF_BATCH, PRT_INNER_MIN, tr.tmin, false);
         } while (wave_count(tr.active) > PRT_K1_KEEP);
     }
+#if PRT_PREFETCH_TOP
+    asm volatile("" ::"v"(tr.pf));
+#endif
     unsigned long long a = wave_sum((unsigned long long)nrays);
     unsigned long long b = wave_sum((unsigned long long)wc.nodes);
     unsigned long long c = wave_sum((unsigned long long)wc.tris);
@@ -903,6 +906,9 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
 #endif
     }
 
+#if PRT_PREFETCH_TOP
+    asm volatile("" ::"v"(tr.pf));
+#endif
     unsigned long long d = wave_sum((unsigned long long)wc.nodes);
     unsigned long long e = wave_sum((unsigned long long)wc.tris);
     unsigned long long f = wave_sum((unsigned long long)wc.tris_full);
