@@ -124,27 +124,39 @@ def main():
             name = wl + ("-f32" if f32 else "")
             st = stats[name]
             blocks = blocks_of(kernel_body(src, feat, f32))
-            # the traversal do-while is the depth-2 loop that holds the node visit (v_alignbit_b32 rotates the packed ranges);
-            # the triangle loop is the depth-3 loop inside it; everything else at depth 1 is the shade pass
+            # Blocks by signature, not by the loop depth LLVM prints (the traversal do-while is merged into the wave loop, so the
+            # node visit shows at depth 1): the NODE VISIT is the block that rotates the packed ranges (>= 10 v_alignbit_b32) and
+            # issues the four 16-byte node loads, plus the stack push / pop blocks that follow it up to the next block with
+            # fp64 work; the TRIANGLE LOOP is the depth-3 loop; the LEAF step is the depth-2 code around it (it has global
+            # loads); everything else inside the wave loop — fp64 helper loops included — is the shade pass.
             unknown = {}
             tot = {"node": [0, 0.0], "leaf": [0, 0.0], "tri": [0, 0.0], "pass": [0, 0.0], "once": [0, 0.0]}
-            in_trav = False
-            for b in blocks:
+            node_at = next(i for i, b in enumerate(blocks)
+                           if sum(1 for x in b["ins"] if x.startswith("v_alignbit")) >= 10 and sum(1 for x in b["ins"] if x.startswith("global_load_dwordx4")) >= 4)
+            node_set = {node_at}
+            for i in range(node_at + 1, len(blocks)):
+                o_ = [x.split()[0] for x in blocks[i]["ins"] if x.startswith("v_")]
+                if any("f64" in o for o in o_) or loop_depth(blocks[i]) >= 2 or len(o_) > 40:
+                    break
+                node_set.add(i)
+            tri_idx = [i for i, b in enumerate(blocks) if loop_depth(b) >= 3]
+            leaf_lo, leaf_hi = (min(tri_idx), max(tri_idx)) if tri_idx else (0, -1)
+            while leaf_lo - 1 >= 0 and loop_depth(blocks[leaf_lo - 1]) == 2 and any(x.startswith("global_load") or x.startswith("v_") for x in blocks[leaf_lo - 1]["ins"]) and leaf_lo - 1 not in node_set:
+                leaf_lo -= 1
+            while leaf_hi + 1 < len(blocks) and loop_depth(blocks[leaf_hi + 1]) == 2 and leaf_hi + 1 not in node_set:
+                leaf_hi += 1
+            for bi, b in enumerate(blocks):
                 d = loop_depth(b)
                 ops = [i.split()[0] for i in b["ins"] if i.startswith("v_")]
-                has_node = any(o.startswith("v_alignbit") for o in ops)
-                if d >= 2 and has_node:
-                    in_trav = True
                 if d == 0:
                     kind = "once"
-                elif d == 1:
-                    kind = "pass"
+                elif bi in node_set:
+                    kind = "node"
                 elif d >= 3:
                     kind = "tri"
+                elif leaf_lo <= bi <= leaf_hi:
+                    kind = "leaf"
                 else:
-                    kind = "node" if has_node or not any("f64" in o or o.startswith("v_div") for o in ops) else "leaf"
-                # depth-2 loops that are NOT the traversal (LDS staging, queue probing, light-tree descent) belong to the pass
-                if d == 2 and not has_node and not any(x in " ".join(b["ins"]) for x in ("ds_read", "ds_write", "global_load_dwordx4")) and len(ops) < 12:
                     kind = "pass"
                 cost = sum(classify(o, cal, w, unknown) for o in ops)
                 tot[kind][0] += len(ops)
