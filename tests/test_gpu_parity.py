@@ -653,6 +653,40 @@ def test_sorted_batch_returns_the_same_hits_in_the_same_places(gpu):
         del sc
 
 
+def test_scenes_give_their_device_memory_back(gpu):
+    """Create / upload / use / destroy, many times over, with every kind of call that allocates on the way (both builders,
+    fp32 tables, the render partial sums, K4's sort scratch, a vertex update): the device's free memory must return to
+    where it was — a renderer that serves frames for days cannot leak per scene."""
+    import torch
+    torch.cuda.synchronize()
+    data = scenes.cornell_box(ball_subdiv=3, width=96, height=96)
+    lo, hi = data.bounds()
+    rays = scenes.random_rays(50_000, lo, hi, seed=2)
+    d_r = torch.from_numpy(rays.view(np.float64).reshape(-1, 8)).cuda()
+    d_h = torch.zeros((rays.shape[0], 4), dtype=torch.float64, device="cuda")
+
+    def cycle(dev):
+        sc = api.Scene(data, device_bvh=dev).upload(0)
+        sc.render(spp=2, max_depth=3)
+        sc.render(spp=2, max_depth=3, precision=1)
+        sc.trace_closest_device(d_r.data_ptr(), rays.shape[0], d_h.data_ptr(), sort=True)
+        sc.trace_closest_device(d_r.data_ptr(), rays.shape[0], d_h.data_ptr(), precision=1)
+        torch.cuda.synchronize()
+        sc.update_vertices(data.vertices * 1.01)
+        sc.render(spp=1, max_depth=2)
+        sc.close()
+
+    for dev in (False, True):  # the first cycles may grow pools inside the runtime: measured after a warm-up
+        cycle(dev)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(12):
+        cycle(bool(k & 1))
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, f"{(free0 - free1) / 2**20:.1f} MiB of device memory did not come back after 12 scene lifetimes"
+
+
 def test_counters_report_the_tree_that_is_resident(gpu):
     """prt_get_counters' static fields follow the tree in use, host- or device-built (r1: bvh_nodes was 0 for device builds)."""
     data = scenes.cornell_box(ball_subdiv=2, width=64, height=64)
