@@ -15,8 +15,9 @@ its size is N.
 
 N>1: the SAME frame is cut into 16x16 tiles dealt diagonally over ranks (strong scaling: total work
 fixed); every rank renders its tiles into a zero-initialised full-size fp32 framebuffer and one RCCL
-reduce(sum) to rank 0 assembles the image (disjoint tiles => x + 0 + ... + 0, bit-identical to the 1-GPU
-image).  The reduce is inside the timed region; consecutive frames alternate between two HIP streams /
+reduce(sum) to rank 0 assembles the image (disjoint tiles => x + 0 + ... + 0: the reduce itself is exact; a share's
+own chunking of the samples makes its fp64 sums differ from the 1-GPU launch's by ~1e-15, invisible in fp32 except
+for about one value in 10^9).  The reduce is inside the timed region; consecutive frames alternate between two HIP streams /
 framebuffers so the next frame fills the GPU while the previous one drains and is being reduced.  After
 the timed region rank 0 renders the frame alone and compares (`assembled_equals_single_rank`), and
 BASELINE config 5 (bathroom2 spp=500 depth=50) is timed the same way (`config5`).
@@ -367,8 +368,14 @@ def time_render(ctx, name, steps, warmup, spp_override=0, with_cpu=True, cpu_tar
             assembled = fb.clone()
             sc.render_device(None, fb.data_ptr(), stream=stream, **dict(render_kw, rank=0, nranks=1))
             torch.cuda.synchronize()
-            # (fp32 fast mode: a share cuts a pixel's samples into other chunks and a chunk's sum is an fp32 one: rounding)
-            out["assembled_equals_single_rank"] = bool(torch.equal(assembled, fb)) if not precision else \
+            # A share deals a pixel's samples in chunks sized for ITS pixel count, so the per-pixel sum of chunk sums groups
+            # the samples differently from the single launch: the fp64 sums agree to ~1e-15 (whole-frame measurement:
+            # profiles/r03_full_frame_variants.json), and the fp32 framebuffer values are the same floats except where that
+            # difference straddles a rounding boundary — about one value in 10^9.  Hence: equal, or within one float ulp
+            # on at most a handful of values.  (fp32 fast mode: a chunk's sum is itself an fp32 one: rtol 1e-5.)
+            differing = int((assembled != fb).sum())
+            out["assembled_differing_values"] = differing
+            out["assembled_equals_single_rank"] = bool(torch.allclose(assembled, fb, rtol=2.5e-7, atol=1e-12) and differing <= 16) if not precision else \
                 bool(torch.allclose(assembled, fb, rtol=1e-5, atol=1e-9))
         # counting instantiation (outside the timed region): node fetches / triangle tests per ray
         torch.cuda.synchronize()
@@ -635,7 +642,7 @@ def main():
                 },
                 "roofline": rf,
             }
-            for k in ("cpu_baseline", "parity_check", "assembled_equals_single_rank"):
+            for k in ("cpu_baseline", "parity_check", "assembled_equals_single_rank", "assembled_differing_values"):
                 if k in w:
                     out[k] = w[k]
             if config5 is not None:

@@ -275,7 +275,8 @@ int prt_render_device(PrtScene* scene, const PrtCamera* cam, const PrtRenderPara
  * bands inside Camera::Render (Source/Camera.cpp:46-71); here the frame is cut into 16x16 tiles dealt over the scenes:
  * scenes[r] is the SAME scene description uploaded to a different device each (prt_scene_upload).  Every device renders
  * its tiles into a zeroed full-size fp32 framebuffer, ONE RCCL reduce(sum, float) to scenes[0]'s device assembles the
- * frame (disjoint tiles: x + 0 + ... + 0, the single-GPU fp32 image bit for bit) and one copy brings it to rgb_f32
+ * frame (disjoint tiles: x + 0 + ... + 0 — an exact reduce; the single-GPU fp32 image bit for bit when sample_chunks is
+ * explicit, else up to the fp64 rounding of a share's own chunking, ~1e-15) and one copy brings it to rgb_f32
  * (W*H*3 floats).  n == 1 is prt_render's fp32 output.  All scenes on ONE device (tile-share replicas) are summed on
  * that device without a collective; any other mix is refused.  If the RCCL communicator cannot be created the call
  * fails (PRT_E_HIP): there is no host-side sum to fall back to.  Communicators are cached per device list.
