@@ -24,8 +24,9 @@ def owned_mask(width, height, tile, rank, nranks):
 
 
 def reduce_framebuffer(fb, dst=0):
-    """Sum the per-rank framebuffers onto `dst`.  Disjoint tiles => every element is x + 0 + ... + 0,
-    so the result is bit-identical to a single-rank render whatever the reduction order."""
+    """Sum the per-rank framebuffers onto `dst`.  Disjoint tiles => every element is x + 0 + ... + 0: the reduce is exact
+    whatever its order, i.e. the frame is the union of the ranks' shares (a share equals the single-rank render's pixels up
+    to how its launch grouped a pixel's samples into chunks)."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.reduce(fb, dst=dst, op=dist.ReduceOp.SUM)
