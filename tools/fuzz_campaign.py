@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch  # noqa: F401
-from pooraytracer_amd import api
+from pooraytracer_amd import api, scenes
 import oracle
 from test_gpu_parity import _random_scene
 
@@ -14,6 +14,7 @@ n = int(os.environ.get("FUZZ_N", "200"))
 first = int(os.environ.get("FUZZ_FIRST", "1000"))
 spp, depth = int(os.environ.get("FUZZ_SPP", "16")), 12
 tot_px = bad_px = 0
+ray_tot = ray_bad = pick_tot = pick_bad = 0
 bad = {}
 t0 = time.time()
 for seed in range(first, first + n):
@@ -30,9 +31,24 @@ for seed in range(first, first + n):
         ys, xs = np.nonzero(b)
         bad[seed] = {"pixels": [[int(x), int(y)] for x, y in zip(xs[:8], ys[:8])], "count": int(b.sum()), "max_rel": float(rel.max())}
         print("seed", seed, bad[seed], flush=True)
+    if os.environ.get("FUZZ_RAYS", "1") == "1":  # closest hits of random rays and light picks, as the per-seed test does
+        lo, hi = data.bounds()
+        rays = scenes.random_rays(20000, lo - 0.3, hi + 0.3, seed=seed + 100)
+        want, got = orc.trace_closest(rays), sc.trace_closest(rays)
+        same = (got["prim"] == want["prim"]) | (got["t"] == want["t"])  # exact ties may name the other triangle
+        hit = want["prim"] >= 0
+        terr = np.abs(got["t"][hit] - want["t"][hit]) / np.maximum(1.0, want["t"][hit])
+        ray_tot += rays.shape[0]
+        ray_bad += int((~same).sum()) + int((terr > 1e-12).sum())
+        org = np.random.default_rng(seed).uniform(-1.5, 1.5, size=(2000, 3))
+        g, c = sc.sample_lights(org, seed=seed), orc.sample_lights(org, seed=seed)
+        pick_tot += org.shape[0]
+        pick_bad += int((g["prim"] != c["prim"]).sum())
     sc.close()
     if (seed - first) % 25 == 24:
         print(f"{seed - first + 1} scenes, {tot_px} pixels, {bad_px} beyond 1e-9, {time.time() - t0:.0f} s", flush=True)
-out = {"scenes": n, "first_seed": first, "spp": spp, "max_depth": depth, "pixels": tot_px, "pixels_beyond_1e-9": bad_px, "seeds_with_differences": bad}
+out = {"scenes": n, "first_seed": first, "spp": spp, "max_depth": depth, "pixels": tot_px, "pixels_beyond_1e-9": bad_px,
+       "random_rays": ray_tot, "rays_with_another_primitive_or_t_beyond_1e-12": ray_bad, "light_picks": pick_tot, "light_picks_differing": pick_bad,
+       "seeds_with_differences": bad}
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03_fuzz_campaign.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "seeds_with_differences"}), flush=True)
