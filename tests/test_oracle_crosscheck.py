@@ -860,3 +860,27 @@ def test_python_raycolor_equals_oracle_on_mixed_materials():
             lit += bool(got.any())
     assert lit > 0.3 * len(px) * spp
     assert {"Gold", "Debug", "Wood", "Mirror", "Light"} <= py.seen, py.seen
+
+
+@pytest.mark.parametrize("seed", [9001, 9002, 9003, 9004])
+def test_python_raycolor_equals_oracle_on_random_scenes(seed):
+    """... and on scenes nobody designed: the random soups of the GPU fuzz test (all material kinds with random parameters,
+    1- / 3- / 4-channel textures, uv outside [0, 1], one or two light meshes, random camera).  tools/crosscheck_campaign.py
+    runs the same comparison over hundreds of seeds (profiles/r03_crosscheck_campaign.json)."""
+    try:
+        from tests.test_gpu_parity import _random_scene
+    except ImportError:
+        from test_gpu_parity import _random_scene
+    data = _random_scene(seed)
+    cam = data.camera
+    orc = oracle.Oracle(data)
+    py = Tracer(data, rr=0.8, background=(0.1, 0.2, 0.3), sample_lights=True)
+    rng = np.random.default_rng(seed)
+    px = [(int(i), int(j)) for i, j in zip(rng.integers(0, cam.width, 30), rng.integers(0, cam.height, 30))]
+    spp, depth = 2, 8
+    want = orc.render_samples(px, spp=spp, max_depth=depth, seed=seed + 3, rr=0.8, background=(0.1, 0.2, 0.3))
+    for k, (i, j) in enumerate(px):
+        for s in range(spp):
+            got = py.sample(cam, i, j, s, seed + 3, depth)
+            err = np.abs(got - want[k, s]).max() / max(1.0, np.abs(want[k, s]).max())
+            assert err <= 1e-12, (seed, i, j, s, got, want[k, s])
