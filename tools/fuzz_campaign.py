@@ -15,6 +15,7 @@ first = int(os.environ.get("FUZZ_FIRST", "1000"))
 spp, depth = int(os.environ.get("FUZZ_SPP", "16")), 12
 tot_px = bad_px = 0
 ray_tot = ray_bad = pick_tot = pick_bad = 0
+smp_tot = smp_bad = sig_bad = 0
 bad = {}
 t0 = time.time()
 for seed in range(first, first + n):
@@ -44,11 +45,22 @@ for seed in range(first, first + n):
         g, c = sc.sample_lights(org, seed=seed), orc.sample_lights(org, seed=seed)
         pick_tot += org.shape[0]
         pick_bad += int((g["prim"] != c["prim"]).sum())
+    if os.environ.get("FUZZ_SAMPLES", "1") == "1":  # per camera sample: radiance and path signature (prt_render_samples hook)
+        cam = data.camera
+        r2 = np.random.default_rng(seed + 7)
+        px = np.stack([r2.integers(0, cam.width, 48), r2.integers(0, cam.height, 48)], axis=1)
+        g, gt = sc.render_samples(px, spp=24, max_depth=depth, seed=seed + 2, trace=True, background=(0.1, 0.2, 0.3))
+        o, ot = orc.render_samples(px, spp=24, max_depth=depth, seed=seed + 2, trace=True, background=(0.1, 0.2, 0.3))
+        relS = (np.abs(g - o) / np.maximum(1.0, np.abs(o))).max(-1)
+        smp_tot += relS.size
+        smp_bad += int((relS > 1e-9).sum())
+        sig_bad += int((~(gt == ot).all(-1)).sum())
     sc.close()
     if (seed - first) % 25 == 24:
         print(f"{seed - first + 1} scenes, {tot_px} pixels, {bad_px} beyond 1e-9, {time.time() - t0:.0f} s", flush=True)
 out = {"scenes": n, "first_seed": first, "spp": spp, "max_depth": depth, "pixels": tot_px, "pixels_beyond_1e-9": bad_px,
        "random_rays": ray_tot, "rays_with_another_primitive_or_t_beyond_1e-12": ray_bad, "light_picks": pick_tot, "light_picks_differing": pick_bad,
+       "camera_samples_compared_one_by_one": smp_tot, "samples_beyond_1e-9": smp_bad, "samples_with_another_path_signature": sig_bad,
        "seeds_with_differences": bad}
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03_fuzz_campaign.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "seeds_with_differences"}), flush=True)
