@@ -808,9 +808,10 @@ def test_render_samples_hook_matches_the_oracle_per_sample(gpu, scene_fn, depth)
     o, ot = orc.render_samples(px, spp=spp, max_depth=depth, seed=4, trace=True)
     rel = np.abs(g - o) / np.maximum(1.0, np.abs(o))
     same = (gt == ot).all(-1)
-    assert (rel.max(-1) <= 1e-9)[same].all()
-    assert same.mean() >= 0.9999, int((~same).sum())       # a knife-edge decision may differ on a sample or two
-    assert (rel.max(-1) <= 1e-9).mean() >= 0.9999
+    # every sample (3,456,000 samples of 3,000 random scenes: no other signature, none beyond 1e-9 — tools/fuzz_campaign.py;
+    # the one event known to differ, a random draw of exactly 0, has its own test below)
+    assert same.all(), int((~same).sum())
+    assert (rel.max(-1) <= 1e-9).all()
     assert (gt[..., 0] >= 1).all() and (gt[..., 0] <= depth + 1).all() and gt[..., 0].max() > 3
     # sub-ranges address the same streams
     g2 = sc.render_samples(px[:5], spp=spp, max_depth=depth, seed=4, sample_begin=17, sample_count=9)
