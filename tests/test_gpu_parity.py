@@ -5,8 +5,9 @@ Tolerances (fp64 arithmetic on both sides; differences come only from FMA contra
   * closest hit: same primitive (except exact-t ties), |dt| <= 1e-12 * max(1,t)
   * light sampling: bit-exact triangle choice, positions to 1e-13
   * rendered image with identical per-sample RNG keys: per-channel |d| <= 1e-9 * max(1,|x|) for every
-    pixel, except that a knife-edge branch (e.g. a shadow test within an ulp of its threshold) may flip
-    a sample; at most 0.1% of pixels may exceed the tolerance and the image mean must agree to 1e-6.
+    pixel.  compare_images would let 1e-4 of the pixels differ (i.e. none on images below 10^4 pixels, a handful on full
+    frames): the one event known to take the other side of a branch is a random draw of exactly 0 (2^-31 per draw, its own
+    test below); nothing else has been seen to differ on whole frames or on 3,000 random scenes.
 """
 import json
 import os
@@ -230,7 +231,7 @@ def test_full_size_properties(gpu):
     assert lit.sum() > 1000
     # a row band rendered by the oracle matches
     cpu, _ = oracle.Oracle(data).render(spp=2, max_depth=20, rows=(500, 504), nthreads=4)
-    compare_images(a[500:504], cpu[500:504], max_bad_frac=2e-3)
+    compare_images(a[500:504], cpu[500:504])
 
 
 def test_closest_hit_optimality_large_soup(gpu):
@@ -294,7 +295,7 @@ def test_full_size_other_configs(gpu, name):
     assert np.isfinite(a).all() and (a >= 0).all()
     assert np.array_equal(a, sc.render(spp=2, max_depth=depth))
     cpu, _ = oracle.Oracle(data).render(spp=2, max_depth=depth, rows=(400, 404), nthreads=8)
-    compare_images(a[400:404], cpu[400:404], max_bad_frac=2e-3)
+    compare_images(a[400:404], cpu[400:404])
 
 
 def _torture_scene():
