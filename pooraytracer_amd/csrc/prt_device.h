@@ -698,6 +698,43 @@ PRT_DEV d3 tex_value(const DScene& S, int ti, real u, real v) {
 // ------------------------------------------------------------------ samplers (RandomNumberGenerator.h:39-73)
 // sin and cos for |x| <= pi/4: the kernel polynomials of fdlibm (k_sin.c / k_cos.c, < 1 ulp), without the range
 // reduction a general sincos() carries.  The concentric map only ever needs this range.
+// a * b + k for a compile-time constant k in fp64: ONE v_fma_f64 with k in a scalar register pair.  Left to itself the
+// compiler keeps every polynomial coefficient of the kernel in a vector register pair for the whole launch (22 registers
+// of a kernel that sits at its register limit) and evaluates a Horner step as v_mov_b64 tmp, k + v_fmac_f64 tmp, a, b —
+// two vector instructions; scalar moves of the literal issue beside the vector stream.
+#ifndef PRT_FMA_KS
+#define PRT_FMA_KS 1
+#endif
+PRT_DEV double fma_ks(double a, double b, double k) {
+#if PRT_FMA_KS && defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+    return r;
+#else
+    return __builtin_fma(a, b, k);
+#endif
+}
+PRT_DEV float fma_ks(float a, float b, float k) { return __builtin_fmaf(a, b, k); }
+// a * k + c and a * k with the constant as the multiplier
+PRT_DEV double fma_sk(double a, double k, double c) {
+#if PRT_FMA_KS && defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
+    return r;
+#else
+    return __builtin_fma(a, k, c);
+#endif
+}
+PRT_DEV double mul_ks(double a, double k) {
+#if PRT_FMA_KS && defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k));
+    return r;
+#else
+    return a * k;
+#endif
+}
+
 PRT_DEV void sincos_quarter(real x, real& sn, real& cs) {
     const real z = x * x;
     if (PRT_F32) { // |x| <= pi/4: Taylor to x^9 / x^8 is below fp32 rounding
@@ -705,11 +742,17 @@ PRT_DEV void sincos_quarter(real x, real& sn, real& cs) {
         cs = RL(1.0) + z * (RL(-0.5) + z * (RL(4.1666667e-02) + z * (RL(-1.3888889e-03) + z * RL(2.4801587e-05))));
         return;
     }
-    const real ps = RL(8.33333333332248946124e-03) + z * (-RL(1.98412698298579493134e-04) + z * (RL(2.75573137070700676789e-06) +
-                      z * (-RL(2.50507602534068634195e-08) + z * RL(1.58969099521155010221e-10))));
-    sn = x + (x * z) * (-RL(1.66666666666666324348e-01) + z * ps);
-    const real pc = z * (RL(4.16666666666666019037e-02) + z * (-RL(1.38888888888741095749e-03) + z * (RL(2.48015872894767294178e-05) +
-                      z * (-RL(2.75573143513906633035e-07) + z * (RL(2.08757232129817482790e-09) + z * -RL(1.13596475577881948265e-11))))));
+    // (each step is fma(z, inner, coefficient), as the contraction of `coefficient + z * inner` was)
+    real ps = fma_ks(z, RL(1.58969099521155010221e-10), -RL(2.50507602534068634195e-08));
+    ps = fma_ks(z, ps, RL(2.75573137070700676789e-06));
+    ps = fma_ks(z, ps, -RL(1.98412698298579493134e-04));
+    ps = fma_ks(z, ps, RL(8.33333333332248946124e-03));
+    sn = x + (x * z) * fma_ks(z, ps, -RL(1.66666666666666324348e-01));
+    real pc = fma_ks(z, -RL(1.13596475577881948265e-11), RL(2.08757232129817482790e-09));
+    pc = fma_ks(z, pc, -RL(2.75573143513906633035e-07));
+    pc = fma_ks(z, pc, RL(2.48015872894767294178e-05));
+    pc = fma_ks(z, pc, -RL(1.38888888888741095749e-03));
+    pc = z * fma_ks(z, pc, RL(4.16666666666666019037e-02));
     cs = RL(1.0) - (RL(0.5) * z - z * pc);
 }
 // sin and cos of 2*pi*u for u in [0,1): the quarter turn nearest to u is subtracted exactly, the remainder
@@ -817,27 +860,28 @@ PRT_DEV double pow_pos(double x, double y) {
     const double f = m - (1.0);
     const double s = fast_div(f, (2.0) + f);
     const double z = s * s, w = z * z;
-    const double t1 = w * fma(w, fma(w, (1.531383769920937332e-01), (2.222219843214978396e-01)), (3.999999999940941908e-01));
-    const double t2 = z * fma(w, fma(w, fma(w, (1.479819860511658591e-01), (1.818357216161805012e-01)), (2.857142874366239149e-01)), (6.666666666666735130e-01));
+    const double t1 = w * fma_ks(w, fma_ks(w, (1.531383769920937332e-01), (2.222219843214978396e-01)), (3.999999999940941908e-01));
+    const double t2 = z * fma_ks(w, fma_ks(w, fma_ks(w, (1.479819860511658591e-01), (1.818357216161805012e-01)), (2.857142874366239149e-01)), (6.666666666666735130e-01));
     const double hfsq = (0.5) * f * f;
     const double dk = (double)k;
-    const double lg = dk * (6.93147180369123816490e-01) - ((hfsq - fma(s, hfsq + (t1 + t2), dk * (1.90821492927058770002e-10))) - f);
+    // (dk * ln2_hi - X is one fma(dk, ln2_hi, -X), as the contraction of the expression was)
+    const double lg = fma_sk(dk, (6.93147180369123816490e-01), -((hfsq - fma(s, hfsq + (t1 + t2), mul_ks(dk, (1.90821492927058770002e-10)))) - f));
     // exp(t): t = n ln2 + r, |r| <= ln2 / 2
     const double t = fmax(y * lg, -(1000.0));
-    const double n = rint(t * (1.44269504088896338700e+00));
-    double r = fma(n, -(6.93147180369123816490e-01), t);
-    r = fma(n, -(1.90821492927058770002e-10), r);
+    const double n = rint(mul_ks(t, (1.44269504088896338700e+00)));
+    double r = fma_sk(n, -(6.93147180369123816490e-01), t);
+    r = fma_sk(n, -(1.90821492927058770002e-10), r);
     double p = (1.6059043836821613e-10);                    // 1/13!
-    p = fma(p, r, (2.08767569878681e-09));                   // 1/12!
-    p = fma(p, r, (2.505210838544172e-08));
-    p = fma(p, r, (2.755731922398589e-07));
-    p = fma(p, r, (2.7557319223985893e-06));
-    p = fma(p, r, (2.48015873015873e-05));
-    p = fma(p, r, (1.984126984126984e-04));
-    p = fma(p, r, (1.388888888888889e-03));
-    p = fma(p, r, (8.333333333333333e-03));
-    p = fma(p, r, (4.1666666666666664e-02));
-    p = fma(p, r, (1.6666666666666666e-01));
+    p = fma_ks(p, r, (2.08767569878681e-09));                   // 1/12!
+    p = fma_ks(p, r, (2.505210838544172e-08));
+    p = fma_ks(p, r, (2.755731922398589e-07));
+    p = fma_ks(p, r, (2.7557319223985893e-06));
+    p = fma_ks(p, r, (2.48015873015873e-05));
+    p = fma_ks(p, r, (1.984126984126984e-04));
+    p = fma_ks(p, r, (1.388888888888889e-03));
+    p = fma_ks(p, r, (8.333333333333333e-03));
+    p = fma_ks(p, r, (4.1666666666666664e-02));
+    p = fma_ks(p, r, (1.6666666666666666e-01));
     p = fma(p, r, (0.5));
     p = fma(p, r, (1.0));
     p = fma(p, r, (1.0));
