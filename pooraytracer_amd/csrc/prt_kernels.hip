@@ -57,7 +57,7 @@
 #define PRT_RENDER_WAVES_PHONG 2 // PhoneReflectance without textures (veach-mis-class scenes)
 #endif
 #ifndef PRT_F32_PK_LEAN
-#define PRT_F32_PK_LEAN 0 // measured: no difference on the lean fp32 kernel
+#define PRT_F32_PK_LEAN 1 // lean kernels too since they have the registers (coefficients in scalar registers): fp64 cornell -0.3 %, fp32 no difference
 #endif
 #ifndef PRT_F32_WAVES
 #define PRT_F32_WAVES 3 // fp32 fast mode: resident waves per SIMD of every K3 permutation
