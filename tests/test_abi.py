@@ -167,7 +167,8 @@ def test_cmake_build_produces_the_same_libraries(tmp_path):
     assert "libpooraytracer_host.so" in ldd and "libprt_hip.so" in ldd
 
 
-@pytest.mark.parametrize("flags", [["-DPRT_BVH_WIDTH=2"], ["-DPRT_TRI_FORM=0", "-DPRT_FAST_F64=0"], ["-DPRT_ITEM_QUEUES=1", "-DPRT_K3_PROFILE=1"], ["-DPRT_POOL=24"]])
+@pytest.mark.parametrize("flags", [["-DPRT_BVH_WIDTH=2"], ["-DPRT_TRI_FORM=0", "-DPRT_FAST_F64=0"], ["-DPRT_ITEM_QUEUES=1", "-DPRT_K3_PROFILE=1"], ["-DPRT_POOL=24"],
+                                   ["-DPRT_FMA_KS=0", "-DPRT_PREFETCH_TOP=1", "-DPRT_F32_PK_LEAN=0"]])
 def test_alternative_build_configurations_still_compile(flags):
     """The A/B switches DESIGN.md quotes measurements for (2-wide nodes, the reference's triangle expressions on 128-byte
     records, IEEE sqrt / division in the shading code, one work-item counter, the per-section profile) are compile-time
