@@ -19,10 +19,13 @@ reduce(sum) to rank 0 assembles the image (disjoint tiles => x + 0 + ... + 0: th
 own chunking of the samples makes its fp64 sums differ from the 1-GPU launch's by ~1e-15, invisible in fp32 except
 for about one value in 10^9).  The reduce is inside the timed region; consecutive frames alternate between two HIP streams /
 framebuffers so the next frame fills the GPU while the previous one drains and is being reduced.  After
-the timed region rank 0 renders the frame alone and compares (`assembled_equals_single_rank`), and
+the timed region rank 0 renders the frame alone and compares (`assembled_matches_single_rank`, `assembled_exact`), and
 BASELINE config 5 (bathroom2 spp=500 depth=50) is timed the same way (`config5`).
 
-Prints ONE JSON line on rank 0.  Extra objects:
+Rank 0 prints TWO JSON lines: first the detailed object (every workload's full entry; also written to bench_detail.json),
+then — as the LAST line, the one the driver parses — a compact object of < 4 KB with the contract's keys, `roofline`
+(bound / achieved / peak / unit / frac / traffic as the bench contract defines them), `cpu_baseline`, `parity_check`,
+`checks_ok` and a one-entry-per-workload `workloads_summary`.  Objects of the detailed line:
   roofline      dominant kernel: what bounds it according to the PMC counters of the same build
                 (profiles/pmc_summary.json, separate rocprofv3 --pmc passes), priced with the launch
                 duration measured live with HIP events on the launch stream.
@@ -210,6 +213,12 @@ def roofline(workload, kernel, bpr, npr, tpr, fpr, rays_per_launch, extra_bytes,
     else:  # no counters for this build yet: the algorithmic figure only, flagged
         out.update(bound="hbm", achieved=round(alg_gbps, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
                    frac=round(alg_gbps / HBM_PEAK_GBPS, 4), traffic=None, note="no PMC summary for this workload")
+    # The object the bench contract asks for, whatever the counters say bounds the launch: ALGORITHMIC bytes of the launch
+    # (SURVEY.md §8(d) per-ray figure x rays of the launch) / the launch's duration against the 8 TB/s HBM peak, with the
+    # counter-measured HBM bytes of the launch beside it.  On cache-resident scenes traffic << algorithmic bytes: the byte
+    # model counts cached bytes there, and the vector-issue fraction (`valu_frac`) is the figure that says how full the chip is.
+    out["contract"] = {"bound": "hbm", "achieved": round(alg_gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": round(alg_gbps / HBM_PEAK_GBPS, 4), "traffic": traffic}
     return out
 
 
@@ -226,23 +235,31 @@ def cpu_model():
 
 def cpu_baseline(scene_data, spp, depth, seed, target_s=8.0):
     """Time the CPU oracle (kind "port") on a bounded sample: centre rows of the same image at the same spp/depth,
-    all host threads as independent row workers with keyed per-sample RNG; plus one row-band single-threaded.
-    Returns (json object, rendered rows image, (y0, y1))."""
+    EVERY core of this process's affinity mask as independent row workers with keyed per-sample RNG (BASELINE.md §3:
+    "all host cores, state N = nproc"); beside it the 16-thread figure earlier rounds reported (when the mask is wider)
+    and one row single-threaded.  Returns (json object, rendered rows image, (y0, y1))."""
     import oracle  # test infrastructure used here only as the reported CPU baseline and as the parity checker
-    threads = max(1, min(len(os.sched_getaffinity(0)), 16))  # the GPU box gives one GPU a 16-core CPU share
+    affinity = len(os.sched_getaffinity(0))
+    threads = max(1, affinity)
     orc = oracle.Oracle(scene_data)
     cam = scene_data.camera
     mid = cam.height // 2
-    t = time.time()
-    _, c = orc.render(spp=8, max_depth=depth, seed=seed, rows=(mid, mid + threads), nthreads=threads)
-    dt = max(time.time() - t, 1e-3)
-    paths_per_s = c["samples"] / dt
-    rows = int(max(threads, min(cam.height, (paths_per_s * target_s) / (cam.width * spp))))
-    rows = max(threads, (rows // threads) * threads)
-    y0 = max(0, mid - rows // 2)
-    t = time.time()
-    img, c = orc.render(spp=spp, max_depth=depth, seed=seed, rows=(y0, y0 + rows), nthreads=threads)
-    dt = time.time() - t
+
+    def band(nthreads, budget_s):
+        """rows around the image centre sized for ~budget_s seconds on nthreads workers"""
+        n0 = min(nthreads, cam.height)
+        t = time.time()
+        _, c = orc.render(spp=8, max_depth=depth, seed=seed, rows=(mid - n0 // 2, mid - n0 // 2 + n0), nthreads=nthreads)
+        dt = max(time.time() - t, 1e-3)
+        pps = c["samples"] / dt
+        rows = int(max(n0, min(cam.height, (pps * budget_s) / (cam.width * spp))))
+        rows = min(cam.height, max(n0, (rows // n0) * n0))
+        y0 = max(0, min(cam.height - rows, mid - rows // 2))
+        t = time.time()
+        img, c = orc.render(spp=spp, max_depth=depth, seed=seed, rows=(y0, y0 + rows), nthreads=nthreads)
+        return img, c, time.time() - t, (y0, y0 + rows), pps
+
+    img, c, dt, rows, paths_per_s = band(threads, target_s)
     rays = c["rays_closest"] + c["rays_shadow"]
     # single thread: a bounded share of one row
     spp1 = max(1, min(spp, int(paths_per_s / threads * 2.0 / cam.width)))
@@ -254,10 +271,12 @@ def cpu_baseline(scene_data, spp, depth, seed, target_s=8.0):
         "unit": "Mrays/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"rows {y0}..{y0 + rows} of the {cam.width}x{cam.height} frame at spp={spp} depth={depth} "
+        "sample": f"rows {rows[0]}..{rows[1]} of the {cam.width}x{cam.height} frame at spp={spp} depth={depth} "
                   f"({c['samples']} camera samples, {rays} rays, {dt:.2f} s, {threads} row-worker threads)",
         "mpaths_per_s": round(c["samples"] / dt / 1e6, 4),
         "seconds": round(dt, 2),
+        "nproc": os.cpu_count(),
+        "affinity_cores": affinity,
         "cpu_model": cpu_model(),
         "single_thread": {"value": round((c1["rays_closest"] + c1["rays_shadow"]) / dt1 / 1e6, 3), "unit": "Mrays/s",
                           "mpaths_per_s": round(c1["samples"] / dt1 / 1e6, 4),
@@ -267,7 +286,12 @@ def cpu_baseline(scene_data, spp, depth, seed, target_s=8.0):
                           "every sample from that hit (Camera.cpp:53-57: the ray is the same for all samples), and does not trace "
                           "rays whose result the reference discards — so compare paths/s (gpu_over_cpu_paths) and s/frame, not rays/s",
     }
-    return out, img, (y0, y0 + rows)
+    if threads > 16:  # the figure rounds 1-3 reported (16 row workers), on a quarter of the budget
+        _, c16, dt16, rows16, _ = band(16, target_s / 4)
+        out["threads16"] = {"value": round((c16["rays_closest"] + c16["rays_shadow"]) / dt16 / 1e6, 3), "unit": "Mrays/s", "cores": 16,
+                            "mpaths_per_s": round(c16["samples"] / dt16 / 1e6, 4),
+                            "sample": f"rows {rows16[0]}..{rows16[1]} ({dt16:.2f} s, 16 row-worker threads)"}
+    return out, img, rows
 
 
 def parity_rows(gpu_f64, ref_img, rows):
@@ -375,7 +399,8 @@ def time_render(ctx, name, steps, warmup, spp_override=0, with_cpu=True, cpu_tar
             # on at most a handful of values.  (fp32 fast mode: a chunk's sum is itself an fp32 one: rtol 1e-5.)
             differing = int((assembled != fb).sum())
             out["assembled_differing_values"] = differing
-            out["assembled_equals_single_rank"] = bool(torch.allclose(assembled, fb, rtol=2.5e-7, atol=1e-12) and differing <= 16) if not precision else \
+            out["assembled_exact"] = differing == 0
+            out["assembled_matches_single_rank"] = bool(torch.allclose(assembled, fb, rtol=2.5e-7, atol=1e-12) and differing <= 16) if not precision else \
                 bool(torch.allclose(assembled, fb, rtol=1e-5, atol=1e-9))
         # counting instantiation (outside the timed region): node fetches / triangle tests per ray
         torch.cuda.synchronize()
@@ -501,7 +526,9 @@ def time_rays(ctx, name, steps, warmup):
                             "value": round(n * steps / els / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(els / steps * 1e3, 3),
                             "device_ms": round(sum(mss) / len(mss), 3),
                             "hits_equal_unsorted": bool(np.array_equal(d_hs.cpu().numpy().view(np.uint64), d_h.cpu().numpy().view(np.uint64))),
-                            "l2_misses_per_ray": {"as_given": 32.2, "sorted": 21.8, "source": "profiles/r03_k4_sorted_pmc.txt (TCC_MISS_sum per launch / 2^24)"}}
+                            "reference_profile": {"note": "NOT measured by this run: L2 misses per ray from an earlier PMC profile",
+                                                  "l2_misses_per_ray_as_given": 32.2, "l2_misses_per_ray_sorted": 21.8,
+                                                  "source": "profiles/r03_k4_sorted_pmc.txt (TCC_MISS_sum per launch / 2^24)"}}
         del d_hs
     if not ctx.args.no_cpu_baseline and data.n_tris <= 200_000:
         import oracle
@@ -520,6 +547,130 @@ def time_rays(ctx, name, steps, warmup):
                                "tolerance": 1e-12, "ok": bool((~same).sum() == 0 and (terr.size == 0 or terr.max() <= 1e-12))}
     sc.close()
     return out
+
+
+# ------------------------------------------------------------------------------------------------ output lines
+COMPACT_LIMIT = 4000  # bytes; the driver keeps a bounded tail of stdout and parses the LAST line (a 24.8 KB line was cut)
+RAY_DEFINITION = ("ray = one BVH traversal executed; the camera ray is traced once per work item since r03 "
+                  "(compare ms_per_step / mpaths_per_s across rounds, not Mrays/s)")
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[: n - 1] + "…"
+
+
+def compact_roofline(rf):
+    """bench contract: {"bound", "achieved", "peak", "unit", "frac", "traffic"} = algorithmic bytes per launch / launch duration
+    against the HBM peak + the PMC-measured HBM bytes per launch; the counter-decided diagnosis rides along in a few scalars."""
+    c = dict(rf.get("contract") or {"bound": "hbm", "achieved": rf.get("algorithmic_gbps"), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                    "frac": rf.get("algorithmic_frac_of_hbm_peak"), "traffic": rf.get("traffic")})
+    c.update(kernel=rf.get("kernel"), kernel_ms=rf.get("kernel_ms"), bytes_per_ray=rf.get("bytes_per_ray"),
+             nodes_per_ray=rf.get("nodes_per_ray"), tris_per_ray=rf.get("tris_per_ray"))
+    if rf.get("bound") == "valu":  # cache-resident launch: what the counters say bounds it
+        c.update(limited_by="valu issue (cache-resident: traffic << algorithmic bytes)", valu_frac=rf.get("frac"),
+                 valu_ginstr_per_s=rf.get("achieved"), valu_peak_ginstr_per_s=rf.get("peak"))
+    elif "frac_of_line_ceiling" in rf:
+        c.update(limited_by="random 128-B line rate", frac_of_line_ceiling=rf["frac_of_line_ceiling"], hbm_frac_measured=rf.get("hbm_frac_measured"))
+    for k in ("pmc_round", "pmc_valu_busy_frac", "pmc_l2_hit_rate"):
+        if k in rf:
+            c[k] = rf[k]
+    return c
+
+
+def compact_cpu_baseline(b):
+    c = {k: b[k] for k in ("value", "unit", "cores", "kind") if k in b}
+    c["sample"] = _short(b.get("sample", ""), 200)
+    for k in ("mpaths_per_s", "nproc", "affinity_cores", "cpu_model", "gpu_over_cpu", "gpu_over_cpu_paths"):
+        if k in b:
+            c[k] = b[k]
+    if "single_thread" in b:
+        c["single_thread_mrays_per_s"] = b["single_thread"]["value"]
+    if "threads16" in b:
+        c["threads16_mrays_per_s"] = b["threads16"]["value"]
+        c["threads16_mpaths_per_s"] = b["threads16"]["mpaths_per_s"]
+    return c
+
+
+def summary_entry(x):
+    rf = x["roofline"]
+    e = {"name": x["workload"], "mrays_per_s": x["value"], "ms_per_step": x["ms_per_step"]}
+    if x.get("mpaths_per_s") is not None:
+        e["mpaths_per_s"] = x["mpaths_per_s"]
+    e["frac"] = rf["contract"]["frac"] if "contract" in rf else rf.get("algorithmic_frac_of_hbm_peak")
+    if rf.get("bound") == "valu":
+        e["valu_frac"] = rf.get("frac")
+    pc = x.get("parity_check", {})
+    e["parity_ok"] = pc.get("ok")
+    if "bad_px" in pc:
+        e["bad_px"] = pc["bad_px"]
+    if "k4_sorted" in x:
+        e["k4_sorted_mrays_per_s"] = x["k4_sorted"]["value"]
+    return e
+
+
+def compact_line(full):
+    """The LAST stdout line: the bench contract's keys + roofline + cpu_baseline + the checks, in < COMPACT_LIMIT bytes.
+    `full` is the detailed object (printed on an earlier line and written to bench_detail.json)."""
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                "vs_baseline", "dtype", "data") if k in full}
+    cfg = dict(full.get("config", {}))
+    if "workload" in cfg:
+        cfg["workload"] = _short(cfg["workload"], 220)
+    out["config"] = cfg
+    if "roofline" in full:
+        out["roofline"] = compact_roofline(full["roofline"])
+    if "cpu_baseline" in full:
+        out["cpu_baseline"] = compact_cpu_baseline(full["cpu_baseline"])
+    for k in ("parity_check", "assembled_matches_single_rank", "assembled_exact", "assembled_differing_values", "checks_ok"):
+        if k in full:
+            out[k] = full[k]
+    if "config5" in full and full["config5"]:
+        c5 = full["config5"]
+        out["config5"] = {"workload": _short(c5.get("config", c5.get("workload")), 160), "value": c5["value"], "unit": c5["unit"],
+                          "ms_per_step": c5["ms_per_step"], "mpaths_per_s": c5.get("mpaths_per_s"), "steps": c5.get("steps"),
+                          "frac": c5["roofline"].get("algorithmic_frac_of_hbm_peak"),
+                          "assembled_matches_single_rank": c5.get("assembled_matches_single_rank"),
+                          "assembled_exact": c5.get("assembled_exact")}
+    for k in ("f32", "k4_sorted"):
+        if k in full:
+            out[k] = {kk: full[k][kk] for kk in ("value", "unit", "ms_per_step") if kk in full[k]}
+            pc = full[k].get("parity_check")
+            if pc:
+                out[k]["parity_ok"] = pc.get("ok")
+            if "hits_equal_unsorted" in full[k]:
+                out[k]["hits_equal_unsorted"] = full[k]["hits_equal_unsorted"]
+    if "workloads_summary" in full:
+        out["workloads_summary"] = full["workloads_summary"]
+    out["detail"] = "bench_detail.json (also the previous stdout line)"
+    # never exceed the limit: shed the optional parts in order of dispensability
+    for shed in ("detail", ("workloads_summary", "optional"), ("cpu_baseline", "sample"), ("config", "parallelism"), "workloads_summary"):
+        if len(json.dumps(out)) <= COMPACT_LIMIT:
+            break
+        if shed == ("workloads_summary", "optional"):
+            out["workloads_summary"] = [{k: e[k] for k in ("name", "mrays_per_s", "ms_per_step", "frac", "parity_ok") if k in e}
+                                        for e in out.get("workloads_summary", [])]
+        elif isinstance(shed, tuple):
+            if shed[0] in out and shed[1] in out[shed[0]]:
+                out[shed[0]][shed[1]] = _short(out[shed[0]][shed[1]], 60)
+        else:
+            out.pop(shed, None)
+    return json.dumps(out)
+
+
+def emit(full):
+    """Detailed object first (one line + bench_detail.json), the compact contract line LAST."""
+    detail = json.dumps(full)
+    try:
+        with open(os.path.join(ROOT, "bench_detail.json"), "w") as f:
+            f.write(detail + "\n")
+    except OSError:
+        pass
+    print(detail, flush=True)
+    line = compact_line(full)
+    assert len(line) <= COMPACT_LIMIT + 96, len(line)
+    print(line, flush=True)
+
 
 
 def main():
@@ -602,7 +753,8 @@ def main():
             if k in w:
                 out[k] = w[k]
         ok = out.get("parity_check", {}).get("ok", True) and out.get("k4_sorted", {}).get("hits_equal_unsorted", True)
-        print(json.dumps(out), flush=True)
+        out["checks_ok"] = bool(ok)
+        emit(out)
     else:
         w = time_render(ctx, args.workload, args.steps, args.warmup, spp_override=args.spp)
         extras, config5 = [], None
@@ -642,34 +794,20 @@ def main():
                 },
                 "roofline": rf,
             }
-            for k in ("cpu_baseline", "parity_check", "assembled_equals_single_rank", "assembled_differing_values"):
+            for k in ("cpu_baseline", "parity_check", "assembled_matches_single_rank", "assembled_exact", "assembled_differing_values"):
                 if k in w:
                     out[k] = w[k]
+            out["config"]["ray_definition"] = RAY_DEFINITION
             if config5 is not None:
                 out["config5"] = config5
             checks = [w] + extras + ([config5] if config5 else [])
-            ok = all(x.get("parity_check", {}).get("ok", True) and x.get("assembled_equals_single_rank", True) and
+            ok = all(x.get("parity_check", {}).get("ok", True) and x.get("assembled_matches_single_rank", True) and
                      x.get("f32", {}).get("parity_check", {}).get("ok", True) and x.get("k4_sorted", {}).get("hits_equal_unsorted", True) for x in checks)
-            out["checks_ok"] = ok
-            # every workload's number in a few hundred bytes, ahead of the detailed entries (a truncated log still carries them)
-            summary = [
-                {"name": x["workload"], "mrays_per_s": x["value"], "ms_per_step": x["ms_per_step"], "mpaths_per_s": x.get("mpaths_per_s"),
-                 "bound": x["roofline"].get("bound"), "frac": x["roofline"].get("frac"),
-                 "parity_ok": x.get("parity_check", {}).get("ok"), "bad_px": x.get("parity_check", {}).get("bad_px"),
-                 **({"k4_sorted_mrays_per_s": x["k4_sorted"]["value"]} if "k4_sorted" in x else {})}
-                for x in checks]
-            # key order of the line: scalars, config, the summary, then the detailed objects
-            head = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                                        "vs_baseline", "dtype", "data", "config")}
-            head["checks_ok"] = ok
-            head["workloads_summary"] = summary
-            head.update({k: v for k, v in out.items() if k not in head})
-            out = head
+            out["checks_ok"] = bool(ok)
+            out["workloads_summary"] = [summary_entry(x) for x in checks]
             if extras:
                 out["workloads"] = extras
-            # ... and once more as the LAST key: whichever end of the line a log keeps, the numbers are in it
-            out["workloads_summary_tail"] = out["workloads_summary"]
-            print(json.dumps(out), flush=True)
+            emit(out)
     if in_group:
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu" if rehearsal else "cuda")
         dist.broadcast(flag, src=0)
@@ -677,7 +815,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
-        raise SystemExit("bench.py: a parity / assembly check failed (see parity_check / assembled_equals_single_rank)")
+        raise SystemExit("bench.py: a parity / assembly check failed (see parity_check / assembled_matches_single_rank)")
 
 
 if __name__ == "__main__":

@@ -219,7 +219,13 @@ def _bench(args, env_extra, timeout=600):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
-    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    raw = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    lines = [json.loads(x) for x in raw]
+    if raw:
+        # the LAST stdout line is the one the driver parses: compact, with the contract's objects
+        assert r.stdout.rstrip().splitlines()[-1] == raw[-1] and len(raw[-1]) < 4096, len(raw[-1])
+        assert {"metric", "value", "unit", "n_gpus", "ms_per_step", "config", "roofline", "checks_ok"} <= set(lines[-1])
+        assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(lines[-1]["roofline"])
     return r, lines
 
 
@@ -229,9 +235,9 @@ def test_bench_two_rank_rehearsal_on_one_gpu(gpu):
     two-stream pipelining off, reduce, max-over-ranks timing, the assembled-image check, one JSON line from rank 0."""
     r, lines = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "6", "--no-cpu-baseline"], {"PRT_BENCH_REHEARSAL": "1"})
     assert r.returncode == 0, r.stderr[-3000:]
-    assert len(lines) == 1
-    out = lines[0]
-    assert out["n_gpus"] == 2 and out["assembled_equals_single_rank"] is True and out["checks_ok"] is True
+    assert len(lines) == 2  # the detailed object, then the compact line
+    out = lines[-1]
+    assert out["n_gpus"] == 2 and out["assembled_matches_single_rank"] is True and out["checks_ok"] is True
     assert out["config"]["parallelism"].startswith("16x16 tiles dealt diagonally over 2 GPU(s)")
     assert out["value"] > 0 and out["roofline"]["kernel"] == "k_render"
 
@@ -244,17 +250,18 @@ def test_bench_two_ranks_over_rccl_when_two_gpus_are_visible(gpu):
         pytest.skip("one GPU visible")
     r, lines = _bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], {}, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = lines[0]
-    assert out["n_gpus"] == 2 and out["assembled_equals_single_rank"] is True
-    assert out["config5"]["assembled_equals_single_rank"] is True and out["checks_ok"] is True
+    out = lines[-1]
+    assert out["n_gpus"] == 2 and out["assembled_matches_single_rank"] is True
+    assert out["config5"]["assembled_matches_single_rank"] is True and out["checks_ok"] is True
 
 
 def test_bench_parity_check_fails_the_run_when_pixels_differ(gpu, monkeypatch):
     """bench.py compares the rows its CPU baseline rendered with a GPU frame of the same configuration and must exit
     non-zero on a mismatch: PRT_BENCH_FAULT=1 makes it compare against a deliberately different seed."""
     r, lines = _bench(["--steps", "1", "--warmup", "0", "--spp", "4", "--no-extra"], {"PRT_BENCH_FAULT": "1"})
-    assert r.returncode != 0 and lines and lines[0]["parity_check"]["ok"] is False and lines[0]["checks_ok"] is False
+    assert r.returncode != 0 and lines and lines[-1]["parity_check"]["ok"] is False and lines[-1]["checks_ok"] is False
     r, lines = _bench(["--steps", "1", "--warmup", "0", "--spp", "4", "--no-extra"], {})
-    pc = lines[0]["parity_check"]
+    pc = lines[-1]["parity_check"]
+    assert lines[-1]["cpu_baseline"]["cores"] == len(os.sched_getaffinity(0)) and lines[-1]["config"]["ray_definition"]
     # a knife-edge branch may flip in a handful of the ~10^6 pixels (tolerance: 0.1 % of them); everything else is within 1e-9
     assert r.returncode == 0 and pc["ok"] is True and pc["bad_px"] <= 1e-4 * pc["pixels"]
