@@ -482,27 +482,76 @@ bool write_png_rgb8(const std::string& path, int w, int h, const std::vector<uin
     chunk(f, "IEND", {});
     return (bool)f;
 }
+// Radiance .hdr as the reference's files are: the reference calls stbi_write_hdr (Camera.cpp:327; nothings/stb
+// stb_image_write.h, an un-vendored submodule — ThirdPartyLibraries/stb is empty, version unpinned).  Its published format is
+// restated here so that a frame written by this library is the same FILE: header with the "Written by" comment and the
+// EXPOSURE line, one "new RLE" scanline (2 2 hi lo) per row, the four RGBE components run-length coded one after the
+// other (runs of >= 3 equal bytes as (128 + n, byte), n <= 127; everything else as literal dumps of <= 128 bytes), flat
+// RGBE pixels for widths outside [8, 32768).  Pinned by the reference's own Results/*.hdr (tests/test_results_pairs.py:
+// the decoded floats of a reference file re-encode to the same bytes).
+void rgbe_of(const float* c, unsigned char* o) {
+    const float m = std::max(c[0], std::max(c[1], c[2]));
+    if (m < 1e-32f) {
+        o[0] = o[1] = o[2] = o[3] = 0;
+    } else {
+        int e;
+        const float s = (float)std::frexp(m, &e) * 256.0f / m;
+        o[0] = (unsigned char)(c[0] * s);
+        o[1] = (unsigned char)(c[1] * s);
+        o[2] = (unsigned char)(c[2] * s);
+        o[3] = (unsigned char)(e + 128);
+    }
+}
+void hdr_scanline(std::vector<unsigned char>& out, int w, const float* rgb, std::vector<unsigned char>& scratch) {
+    unsigned char px[4];
+    if (w < 8 || w >= 32768) {
+        for (int x = 0; x < w; ++x) {
+            rgbe_of(rgb + 3 * x, px);
+            out.insert(out.end(), px, px + 4);
+        }
+        return;
+    }
+    scratch.resize((size_t)w * 4);
+    for (int x = 0; x < w; ++x) {
+        rgbe_of(rgb + 3 * x, px);
+        for (int c = 0; c < 4; ++c) scratch[(size_t)c * w + x] = px[c];
+    }
+    const unsigned char head[4] = {2, 2, (unsigned char)((w >> 8) & 0xFF), (unsigned char)(w & 0xFF)};
+    out.insert(out.end(), head, head + 4);
+    for (int c = 0; c < 4; ++c) {
+        const unsigned char* comp = &scratch[(size_t)c * w];
+        int x = 0;
+        while (x < w) {
+            int r = x; // start of the next run of three equal bytes (or the end of the row)
+            while (r + 2 < w && !(comp[r] == comp[r + 1] && comp[r] == comp[r + 2])) ++r;
+            const bool run = r + 2 < w;
+            if (!run) r = w;
+            while (x < r) { // literals up to the run
+                const int n = std::min(128, r - x);
+                out.push_back((unsigned char)n);
+                out.insert(out.end(), comp + x, comp + x + n);
+                x += n;
+            }
+            if (run) {
+                while (r < w && comp[r] == comp[x]) ++r;
+                while (x < r) {
+                    const int n = std::min(127, r - x);
+                    out.push_back((unsigned char)(n + 128));
+                    out.push_back(comp[x]);
+                    x += n;
+                }
+            }
+        }
+    }
+}
 bool write_hdr(const std::string& path, int w, int h, const std::vector<float>& rgb) {
     std::ofstream f(path, std::ios::binary);
     if (!f) return false;
-    f << "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y " << h << " +X " << w << "\n";
-    std::vector<unsigned char> px((size_t)w * h * 4);
-    for (size_t i = 0; i < (size_t)w * h; ++i) {
-        const float r = rgb[i * 3], g = rgb[i * 3 + 1], b = rgb[i * 3 + 2];
-        const float m = std::max(r, std::max(g, b));
-        unsigned char* o = &px[i * 4];
-        if (!(m > 1e-32f)) {
-            o[0] = o[1] = o[2] = o[3] = 0;
-        } else {
-            int e;
-            const float s = std::frexp(m, &e) * 256.0f / m;
-            o[0] = (unsigned char)(r * s);
-            o[1] = (unsigned char)(g * s);
-            o[2] = (unsigned char)(b * s);
-            o[3] = (unsigned char)(e + 128);
-        }
-    }
-    f.write(reinterpret_cast<const char*>(px.data()), (std::streamsize)px.size());
+    f << "#?RADIANCE\n# Written by stb_image_write.h\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=          1.0000000000000\n\n-Y " << h << " +X " << w << "\n";
+    std::vector<unsigned char> out, scratch;
+    out.reserve((size_t)w * h * 3);
+    for (int y = 0; y < h; ++y) hdr_scanline(out, w, &rgb[(size_t)y * w * 3], scratch);
+    f.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)out.size());
     return (bool)f;
 }
 double linear_to_srgb(double c) { // Camera.cpp:214-221
