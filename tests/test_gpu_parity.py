@@ -5,9 +5,9 @@ Tolerances (fp64 arithmetic on both sides; differences come only from FMA contra
   * closest hit: same primitive (except exact-t ties), |dt| <= 1e-12 * max(1,t)
   * light sampling: bit-exact triangle choice, positions to 1e-13
   * rendered image with identical per-sample RNG keys: per-channel |d| <= 1e-9 * max(1,|x|) for every
-    pixel.  compare_images would let 1e-4 of the pixels differ (i.e. none on images below 10^4 pixels, a handful on full
-    frames): the one event known to take the other side of a branch is a random draw of exactly 0 (2^-31 per draw, its own
-    test below); nothing else has been seen to differ on whole frames or on 3,000 random scenes.
+    pixel.  compare_images allows NO pixel beyond it on images below 10^5 pixels and two on whole frames: the one event known
+    to take the other side of a branch is a random draw of exactly 0 (2^-31 per draw, its own test below); nothing else has
+    been seen to differ on whole frames or on 3,000 random scenes.
 """
 import json
 import os
@@ -38,10 +38,15 @@ def compare_hits(g, o):
     assert np.isinf(g["t"][~hit]).all()
 
 
-def compare_images(gpu_img, cpu_img, max_bad_frac=1e-4):  # observed since round 3: no pixel beyond 1e-9 anywhere
+def compare_images(gpu_img, cpu_img, max_bad=None):
+    """Every pixel within 1e-9 per channel.  `max_bad` is an ABSOLUTE pixel count: 0 on anything below 10^5 pixels, 2 on whole
+    frames (the one event known to take the other side of a branch is a random draw of exactly 0, 2^-31 per draw: about one
+    pixel per 10^9 samples — DESIGN.md §3; nothing else has been seen to differ on whole frames or on 3,000 random scenes)."""
     tol = 1e-9 * np.maximum(1.0, np.abs(cpu_img))
     bad = (np.abs(gpu_img - cpu_img) > tol).any(axis=-1)
-    assert bad.mean() <= max_bad_frac, f"{bad.sum()} of {bad.size} pixels differ"
+    if max_bad is None:
+        max_bad = 0 if bad.size < 100_000 else 2
+    assert bad.sum() <= max_bad, f"{bad.sum()} of {bad.size} pixels differ: {np.argwhere(bad)[:8].tolist()}"
     assert np.allclose(gpu_img.mean(axis=(0, 1)), cpu_img.mean(axis=(0, 1)), rtol=2e-3)
     if bad.sum() == 0:
         assert np.allclose(gpu_img.mean(axis=(0, 1)), cpu_img.mean(axis=(0, 1)), rtol=1e-9)
@@ -936,3 +941,24 @@ def test_the_one_pixel_of_the_headline_frame_that_differs_is_the_zero_draw(gpu):
     stream = oracle.rng_stream(1, 161 * cam.width + 296, 465, 8)
     assert stream[5] == 0.0                        # draws 0-3 light pick, 4 roulette, 5-6 the cosine sample: u.y = 0 -> r = -1
     assert gt[0, 465, 1] == ot[0, 465, 1] and gt[0, 465, 2] == ot[0, 465, 2]   # same camera vertex, same decisions there
+
+
+@pytest.mark.parametrize("name,factory,depth", [("cornell-box", "cornell_box", 20), ("veach-mis", "veach_mis", 100), ("bathroom2", "bathroom", 50)])
+def test_whole_frame_equals_the_oracle_on_every_pixel(gpu, name, factory, depth):
+    """whole-frame parity under the driver's eyes.  The three BASELINE scenes at their full resolution and
+    their configuration's depth, spp 8, EVERY pixel against the oracle's frame (all host threads as row workers,
+    Camera.cpp:46-71's split): none beyond 1e-9 — and nothing near it (observed maxima ~1e-13, rounding order only)."""
+    data = getattr(scenes, factory)()
+    cam = data.camera
+    sc = api.Scene(data).upload(gpu)
+    orc = oracle.Oracle(data)
+    ref, ocnt = orc.render(spp=8, max_depth=depth, seed=1, nthreads=min(64, len(os.sched_getaffinity(0))))
+    img = sc.render(spp=8, max_depth=depth, seed=1)
+    assert img.shape == ref.shape == (cam.height, cam.width, 3)
+    rel = np.abs(img - ref) / np.maximum(1.0, np.abs(ref))
+    bad = (rel > 1e-9).any(-1)
+    assert bad.sum() == 0, (name, int(bad.sum()), np.argwhere(bad)[:8].tolist(), float(rel.max()))
+    assert rel.max() <= 1e-10, float(rel.max())
+    cnt = sc.counters()
+    assert cnt["samples"] == ocnt["samples"] == cam.width * cam.height * 8
+    sc.close()
