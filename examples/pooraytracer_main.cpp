@@ -11,6 +11,7 @@
 
 #include "pooraytracer/BVH.h"
 #include "pooraytracer/Camera.h"
+#include "prt.h"
 #include "pooraytracer/Model.h"
 
 int main(int argc, char** argv) {
@@ -57,6 +58,7 @@ int main(int argc, char** argv) {
         std::printf("%s: %zu meshes, %dx%d %s, %.3f s (first Render includes BVH build + upload), %llu rays, kernel %.2f ms -> %s\n",
                     fileName.c_str(), model->meshes.size(), camera.imageWidth, camera.imageHeight,
                     camera.GetParametersStr().c_str(), sec, camera.lastRays, camera.lastKernelMs, png.c_str());
+        prt_shutdown(); // releases the RCCL communicators a multi-device Camera::devices render cached (no-op otherwise)
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());

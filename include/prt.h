@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PRT_ABI_VERSION 4
+#define PRT_ABI_VERSION 5
 
 /* error codes */
 #define PRT_OK 0
@@ -188,11 +188,27 @@ typedef struct PrtBvhInfo {
     uint32_t width;      /* children per node */
     uint32_t tri_bytes;  /* payload of one intersection record: 32 (plane: n, D) + the part read after the interval test */
     uint32_t tri_stride; /* bytes between records in HBM once uploaded (0 before): tri_bytes, or 128 for scenes that stream from HBM */
+    /* image textures as resident on the device (0 before upload; ImageTexture::Value, Source/Texture.cpp:22-71).  A texture is
+     * stored as bilinear footprints (per texel cell the four taps of a lookup: 128 bytes per texel, one line per lookup) while
+     * the scene's footprints stay within 256 MiB, smallest texture first; larger ones stay plain texel arrays (24 bytes per
+     * texel).  The fp32 fast mode adds a float copy of half the size on first use. */
+    uint64_t texture_bytes;           /* fp64 bytes of all texel arrays */
+    uint64_t texture_footprint_bytes; /* ... of which footprint records */
+    uint32_t texture_layouts;         /* bit 0: a texture is stored as footprints; bit 1: one is stored as plain texels */
+    /* how the fp64 render kernel (K3) of this scene is launched (0 before upload) */
+    uint32_t render_blocks_per_cu;    /* resident 256-thread blocks per CU (= waves per SIMD) of the production instantiation */
+    uint32_t render_blocks_wanted;    /* ... the register allocation of the scene's material permutation leaves room for */
+    uint32_t lds_materials, lds_light_nodes, lds_light_tris; /* shading tables K3 stages in LDS (0: read from global memory) */
+    uint32_t stack_need;              /* traversal stack entries this tree can need (<= 40, the builders' bound) */
+    uint32_t reserved_;
 } PrtBvhInfo;
 
 typedef struct PrtScene PrtScene;
 
 int prt_abi_version(void);
+/* 1 when this build reads the developer / test environment hooks (PRT_TUNE_*, PRT_TEST_*; -DPRT_DEV_HOOKS=1 builds only —
+ * libprt_hip_dev.so of the test suite).  The shipped libprt_hip.so returns 0 and reads no environment variable. */
+int prt_dev_hooks(void);
 const char* prt_last_error(void);
 int prt_device_count(int* n);
 
@@ -278,10 +294,17 @@ int prt_render_device(PrtScene* scene, const PrtCamera* cam, const PrtRenderPara
  * frame (disjoint tiles: x + 0 + ... + 0 — an exact reduce; the single-GPU fp32 image bit for bit when sample_chunks is
  * explicit, else up to the fp64 rounding of a share's own chunking, ~1e-15) and one copy brings it to rgb_f32
  * (W*H*3 floats).  n == 1 is prt_render's fp32 output.  All scenes on ONE device (tile-share replicas) are summed on
- * that device without a collective; any other mix is refused.  If the RCCL communicator cannot be created the call
- * fails (PRT_E_HIP): there is no host-side sum to fall back to.  Communicators are cached per device list.
+ * that device without a collective; any other mix is refused.  If the RCCL communicator cannot be created, or the
+ * reduce fails, the call fails (PRT_E_HIP): there is no host-side sum to fall back to; the scenes stay usable and the
+ * caller's current HIP device is restored on every way out.  Communicators are cached per device list until prt_shutdown.
+ * EXPERIMENTAL for n > 1 on different devices: that branch has so far only run with a communicator of one rank (no
+ * multi-GPU box was available to rounds 1-4).  The result has fp32 precision (the element type of the reduce), where
+ * prt_render's rgb_f64 is the fp64 frame.
  */
 int prt_render_multi(PrtScene* const* scenes, int n, const PrtCamera* cam, const PrtRenderParams* params, float* rgb_f32);
+/* Releases process-wide state: the RCCL communicators prt_render_multi cached (ncclCommDestroy).  Scenes are untouched.
+ * Call before exit after multi-device renders; may be called repeatedly, and prt_render_multi re-creates what it needs. */
+void prt_shutdown(void);
 
 /*
  * Test hook: RayColor of single camera samples through K3 itself (the production instantiation of k_render when `trace`

@@ -5,7 +5,7 @@ tests/test_abi.py checks sizes and that every declared symbol is exported.
 """
 import ctypes as C
 
-PRT_ABI_VERSION = 4
+PRT_ABI_VERSION = 5
 TRACE_WORDS, TRACE_VERTS = 64, 31           # prt.h PRT_TRACE_*
 TRACE_NEE, TRACE_VISIBLE, TRACE_ROULETTE, TRACE_SCATTER = 1, 2, 4, 8
 PRECISION_F64, PRECISION_F32 = 0, 1
@@ -89,6 +89,16 @@ class PrtBvhInfo(C.Structure):
         ("width", C.c_uint32),
         ("tri_bytes", C.c_uint32),
         ("tri_stride", C.c_uint32),
+        ("texture_bytes", C.c_uint64),
+        ("texture_footprint_bytes", C.c_uint64),
+        ("texture_layouts", C.c_uint32),
+        ("render_blocks_per_cu", C.c_uint32),
+        ("render_blocks_wanted", C.c_uint32),
+        ("lds_materials", C.c_uint32),
+        ("lds_light_nodes", C.c_uint32),
+        ("lds_light_tris", C.c_uint32),
+        ("stack_need", C.c_uint32),
+        ("reserved_", C.c_uint32),
     ]
 
 
@@ -177,6 +187,8 @@ assert LIGHT_SAMPLE_DTYPE.itemsize == C.sizeof(PrtLightSample) == 64
 # every symbol include/prt.h declares
 EXPORTS = [
     "prt_abi_version",
+    "prt_dev_hooks",
+    "prt_shutdown",
     "prt_render_samples",
     "prt_render_multi",
     "prt_last_error",

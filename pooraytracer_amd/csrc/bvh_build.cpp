@@ -249,17 +249,12 @@ bool validate_nodes(const DNode* nodes, size_t n_nodes, size_t n_tris, std::stri
         st.pop_back();
         int32_t refs[4];
         int nr = 0;
-#if PRT_BVH_WIDTH == 4
         for (int c = 0; c < 4; ++c)
             if (nodes[i].ref[c] != (int32_t)0x80000000) {
                 if (c != nr) return bad("unused slot before a used one"); // the traversal only checks the refs of slots 2 and 3
                 refs[nr++] = nodes[i].ref[c];
             }
         if (n_tris == 1 && nr == 2 && refs[1] == refs[0]) nr = 1; // the one-triangle root lists its leaf twice
-#else
-        refs[nr++] = nodes[i].ref0;
-        if (!(n_tris == 1 && nodes[i].ref1 == nodes[i].ref0)) refs[nr++] = nodes[i].ref1;
-#endif
         if (phase == 0) {
             if (++visited > n_nodes) return bad("cycle or shared node");
             if (nr < 1) return bad("node without children");
@@ -304,13 +299,8 @@ int tree_stack_need(const DNode* nodes, size_t n_nodes) {
         st.pop_back();
         int32_t refs[4];
         int nr = 0;
-#if PRT_BVH_WIDTH == 4
         for (int c = 0; c < 4; ++c)
             if (nodes[i].ref[c] != (int32_t)0x80000000) refs[nr++] = nodes[i].ref[c];
-#else
-        refs[nr++] = nodes[i].ref0;
-        if (nodes[i].ref1 != nodes[i].ref0) refs[nr++] = nodes[i].ref1;
-#endif
         if (phase == 0) {
             st.push_back({i, 1});
             for (int c = 0; c < nr; ++c)
@@ -376,10 +366,6 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
     out.order.resize(n);
     for (size_t i = 0; i < n; ++i) out.order[i] = b.prims[i].idx;
 
-#if PRT_BVH_WIDTH != 4
-    out.nodes.resize(fn.size());
-#endif
-#if PRT_NODE16
     // quantisation grid over the root box: coordinate(q) = g0 + q * gs, evaluated in double here; the
     // kernel's float evaluation error is covered by its per-ray pad.  lo rounds down, hi rounds up.
     double g0[3], gs[3];
@@ -400,7 +386,6 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
         while (q < 65535 && g0[a] + q * gs[a] < (double)v) q += 1;
         return (uint16_t)q;
     };
-#if PRT_BVH_WIDTH == 4
     {
         // heights of the binary subtrees (children follow their parent in the pre-order array)
         std::vector<uint8_t> h2(fn.size(), 1);
@@ -498,34 +483,10 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
         out.nodes_shallow.clear();
         if (out.stack_need > PRT_STACK_SHALLOW) collapse(PRT_STACK_SHALLOW, out.nodes_shallow);
     }
-#else
-    for (size_t i = 0; i < fn.size(); ++i) {
-        const FNode& f = fn[i];
-        DNode& d = out.nodes[i];
-        d.c0x[0] = qlo(f.c0x[0], 0); d.c0x[1] = qhi(f.c0x[1], 0);
-        d.c0y[0] = qlo(f.c0y[0], 1); d.c0y[1] = qhi(f.c0y[1], 1);
-        d.c0z[0] = qlo(f.c0z[0], 2); d.c0z[1] = qhi(f.c0z[1], 2);
-        d.c1x[0] = qlo(f.c1x[0], 0); d.c1x[1] = qhi(f.c1x[1], 0);
-        d.c1y[0] = qlo(f.c1y[0], 1); d.c1y[1] = qhi(f.c1y[1], 1);
-        d.c1z[0] = qlo(f.c1z[0], 2); d.c1z[1] = qhi(f.c1z[1], 2);
-        d.ref0 = f.ref0;
-        d.ref1 = f.ref1;
-    }
-#endif
     float gm = 0.f; // the dequantised coordinates can exceed the fp32 boxes by one grid step
     for (int a = 0; a < 3; ++a)
         gm = std::max(gm, std::max(std::fabs(out.grid_origin[a]), std::fabs((float)(g0[a] + 65535.0 * gs[a]))));
     out.coord_scale = std::nextafter(std::max(out.coord_scale, gm), std::numeric_limits<float>::infinity());
-#else
-    for (size_t i = 0; i < fn.size(); ++i) {
-        const FNode& f = fn[i];
-        DNode& d = out.nodes[i];
-        std::memset(&d, 0, sizeof(d));
-        std::memcpy(d.c0x, f.c0x, sizeof(float) * 12);
-        d.ref0 = f.ref0;
-        d.ref1 = f.ref1;
-    }
-#endif
     return true;
 }
 

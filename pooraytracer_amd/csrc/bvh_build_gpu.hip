@@ -322,7 +322,6 @@ __device__ inline uint16_t quant_hi(const Grid& g, float v, int a) {
     return (uint16_t)q;
 }
 
-#if PRT_BVH_WIDTH == 4
 // Heights of the binary subtrees, one launch per level from the deepest up (nodes of one level are contiguous:
 // the split launches allocate them level by level).
 __global__ void k_heights(const FNodeD* __restrict__ fn, uint32_t first, uint32_t count, uint8_t* __restrict__ h2) {
@@ -405,35 +404,6 @@ __global__ void k_collapse_level(const Open* __restrict__ in, Open* __restrict__
     }
     wide[o.slot] = d;
 }
-#else
-__global__ void k_quantise(const FNodeD* __restrict__ fn, uint32_t n_nodes, Grid g, DNode* __restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    const FNodeD f = fn[i];
-    DNode d;
-#if PRT_NODE16
-    auto qlo = [&](float v, int a) -> uint16_t { return quant_lo(g, v, a); };
-    auto qhi = [&](float v, int a) -> uint16_t { return quant_hi(g, v, a); };
-    d.c0x[0] = qlo(f.c[0].lo[0], 0); d.c0x[1] = qhi(f.c[0].hi[0], 0);
-    d.c0y[0] = qlo(f.c[0].lo[1], 1); d.c0y[1] = qhi(f.c[0].hi[1], 1);
-    d.c0z[0] = qlo(f.c[0].lo[2], 2); d.c0z[1] = qhi(f.c[0].hi[2], 2);
-    d.c1x[0] = qlo(f.c[1].lo[0], 0); d.c1x[1] = qhi(f.c[1].hi[0], 0);
-    d.c1y[0] = qlo(f.c[1].lo[1], 1); d.c1y[1] = qhi(f.c[1].hi[1], 1);
-    d.c1z[0] = qlo(f.c[1].lo[2], 2); d.c1z[1] = qhi(f.c[1].hi[2], 2);
-#else
-    d.c0x[0] = f.c[0].lo[0]; d.c0x[1] = f.c[0].hi[0];
-    d.c0y[0] = f.c[0].lo[1]; d.c0y[1] = f.c[0].hi[1];
-    d.c0z[0] = f.c[0].lo[2]; d.c0z[1] = f.c[0].hi[2];
-    d.c1x[0] = f.c[1].lo[0]; d.c1x[1] = f.c[1].hi[0];
-    d.c1y[0] = f.c[1].lo[1]; d.c1y[1] = f.c[1].hi[1];
-    d.c1z[0] = f.c[1].lo[2]; d.c1z[1] = f.c[1].hi[2];
-    d.pad[0] = d.pad[1] = 0;
-#endif
-    d.ref0 = f.ref[0];
-    d.ref1 = f.ref[1];
-    out[i] = d;
-}
-#endif // PRT_BVH_WIDTH
 
 struct Scratch { // frees every temporary on every exit path
     std::vector<void*> p;
@@ -584,7 +554,6 @@ bool build_bvh_device(const PrimBox* h_boxes, size_t n_, DeviceBVH& out, std::st
     Grid g;
     quant_grid(root_box.lo, root_box.hi, false, g.origin, g.step);
     DNode* d_nodes = nullptr;
-#if PRT_BVH_WIDTH == 4
     uint32_t n_out = 0, out_depth = 0;
     {
         // binary nodes of level L occupy [first[L], first[L] + counts[L+1]/2): heights bottom-up, then the collapse
@@ -646,18 +615,6 @@ bool build_bvh_device(const PrimBox* h_boxes, size_t n_, DeviceBVH& out, std::st
     }
     hs.n_nodes = n_out;
     hs.depth = out_depth;
-#else
-    BVH_HIP(hipMalloc(reinterpret_cast<void**>(&d_nodes), std::max<size_t>((size_t)hs.n_nodes * sizeof(DNode), 256)));
-    k_quantise<<<blocks(hs.n_nodes), B, 0, st>>>(d_fn, hs.n_nodes, g, d_nodes);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipEventRecord(ev[4], st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) {
-        (void)hipFree(d_nodes);
-        if (err) *err = std::string("device BVH build: ") + hipGetErrorString(e);
-        return false;
-    }
-#endif
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev[0], ev[1]); out.ms_sort = ms;
     (void)hipEventElapsedTime(&ms, ev[1], ev[2]); out.ms_tree = ms;
@@ -676,12 +633,10 @@ bool build_bvh_device(const PrimBox* h_boxes, size_t n_, DeviceBVH& out, std::st
     float cs = 0.f;
     for (int a = 0; a < 3; ++a) cs = std::max(cs, std::max(std::fabs(root_box.lo[a]), std::fabs(root_box.hi[a])));
     cs = std::nextafter(cs, std::numeric_limits<float>::infinity());
-#if PRT_NODE16
     float gm = 0.f; // the dequantised coordinates can exceed the fp32 boxes by one grid step
     for (int a = 0; a < 3; ++a)
         gm = std::max(gm, std::max(std::fabs(g.origin[a]), std::fabs((float)((double)g.origin[a] + 65535.0 * (double)g.step[a]))));
     cs = std::nextafter(std::max(cs, gm), std::numeric_limits<float>::infinity());
-#endif
     out.coord_scale = cs;
     return true;
 }

@@ -70,7 +70,21 @@ int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+// Developer / test hooks are environment variables (PRT_TUNE_*: scheduling thresholds, table sizes, layouts for A/B runs;
+// PRT_TEST_*: failure injection; PRT_VALIDATE_BVH).  The shipped libprt_hip.so does NOT read them: only a build with
+// -DPRT_DEV_HOOKS=1 does (pooraytracer_amd/build.py builds that one as libprt_hip_dev.so for the tests and sweep tools
+// that need it), so no environment variable can change what the production library schedules or make it fail.
+#ifndef PRT_DEV_HOOKS
+#define PRT_DEV_HOOKS 0
+#endif
+#if PRT_DEV_HOOKS
+const char* dev_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* dev_env(const char*) { return nullptr; } // (not constexpr: call sites pass the result on to atoi)
+#endif
 } // namespace
+
+extern "C" int prt_dev_hooks(void) { return PRT_DEV_HOOKS; }
 
 #define PRT_HIP(call)                                                                                   \
     do {                                                                                                \
@@ -86,7 +100,9 @@ struct PrtScene {
     std::vector<DMaterial> mats;
     std::vector<DTexture> texs;
     std::vector<double> texels_lin; // GetPixel() of every texel (Texture.cpp:50-65)
-    size_t n_texel_reals = 0;       // reals of the footprint array resident on the device (16 per texel)
+    size_t n_texel_reals = 0;       // reals of the texel array resident on the device (16 per texel as footprints, 3 as plain texels)
+    size_t tex_footprint_bytes = 0; // ... of which footprint records (fp64 bytes)
+    uint32_t tex_layouts = 0;       // bit 0: some texture is stored as footprints, bit 1: some as plain texels
     prt::LightTree lights;
     prt::BuiltBVH bvh;
     std::vector<uint64_t> mesh_first; // mesh structure, kept for prt_scene_update_vertices
@@ -99,6 +115,7 @@ struct PrtScene {
     int device = -1;
     int n_cu = 0;
     int blocks_per_cu[2] = {0, 0};
+    int blocks_wanted = 0; // what the production kernel's register allocation allows (occupancy without LDS tables)
     int ltri_lds = 0;
     int light_lds = 0, mat_lds = 0; // light-tree nodes / materials staged in LDS by K3 (both 0 = the kernels without LDS tables)
     int feat = 0; // material features of the scene (1 textures, 2 Phong, 4 CookTorrance) -> K3 permutation
@@ -320,6 +337,17 @@ int prt_scene_bvh_info(const PrtScene* s, PrtBvhInfo* out) {
     out->width = PRT_BVH_WIDTH;
     out->tri_bytes = (uint32_t)sizeof(DTri);
     out->tri_stride = s->device >= 0 ? s->d.tri_stride : 0u;
+    out->texture_bytes = s->device >= 0 ? (uint64_t)s->n_texel_reals * sizeof(double) : 0u;
+    out->texture_footprint_bytes = s->device >= 0 ? (uint64_t)s->tex_footprint_bytes : 0u;
+    out->texture_layouts = s->device >= 0 ? s->tex_layouts : 0u;
+    const bool up = s->device >= 0;
+    out->render_blocks_per_cu = up ? (uint32_t)s->blocks_per_cu[0] : 0u;
+    out->render_blocks_wanted = up ? (uint32_t)s->blocks_wanted : 0u;
+    out->lds_materials = up ? (uint32_t)s->mat_lds : 0u;
+    out->lds_light_nodes = up ? (uint32_t)s->light_lds : 0u;
+    out->lds_light_tris = up ? (uint32_t)s->ltri_lds : 0u;
+    out->stack_need = up ? (uint32_t)s->stack_need : 0u;
+    out->reserved_ = 0;
     return PRT_OK;
 }
 
@@ -342,7 +370,7 @@ static int upload_impl(PrtScene* s, int device);
 // bytes a block may spend on them (record sizes differ between the fp64 and the fp32 kernels).
 static void size_tables(const PrtScene* s, int budget, size_t mat_bytes, size_t ltri_bytes, size_t lnode_bytes, int* mat, int* ltri, int* light) {
     *mat = *ltri = *light = 0;
-    const bool off = std::getenv("PRT_TUNE_NO_LDS") && std::atoi(std::getenv("PRT_TUNE_NO_LDS"));
+    const bool off = dev_env("PRT_TUNE_NO_LDS") && std::atoi(dev_env("PRT_TUNE_NO_LDS"));
     if (off || s->mats.empty() || s->mats.size() * mat_bytes > 8192 || (int)(s->mats.size() * mat_bytes) > budget) return;
     *mat = (int)s->mats.size();
     budget -= *mat * (int)mat_bytes;
@@ -351,8 +379,8 @@ static void size_tables(const PrtScene* s, int budget, size_t mat_bytes, size_t 
         budget -= *ltri * (int)ltri_bytes;
     }
     *light = (int)std::min<size_t>(s->lights.nodes.size(), (size_t)(std::max(budget, 0) / (int)lnode_bytes));
-    if (const char* e = std::getenv("PRT_TUNE_LIGHT_LDS")) *light = std::min(*light, std::max(0, std::atoi(e)));
-    if (const char* e = std::getenv("PRT_TUNE_LTRI_LDS")) if (!std::atoi(e)) *ltri = 0;
+    if (const char* e = dev_env("PRT_TUNE_LIGHT_LDS")) *light = std::min(*light, std::max(0, std::atoi(e)));
+    if (const char* e = dev_env("PRT_TUNE_LTRI_LDS")) if (!std::atoi(e)) *ltri = 0;
 }
 
 // Either the whole scene is resident afterwards, or nothing is: a failure anywhere (allocation, copy, device build)
@@ -377,7 +405,7 @@ static int upload_impl(PrtScene* s, int device) {
     PRT_HIP(hipSetDevice(device));
     s->device = device;
     s->n_uploads = 0;
-    s->fail_upload_at = std::getenv("PRT_TEST_FAIL_UPLOAD") ? std::atoi(std::getenv("PRT_TEST_FAIL_UPLOAD")) : -1;
+    s->fail_upload_at = dev_env("PRT_TEST_FAIL_UPLOAD") ? std::atoi(dev_env("PRT_TEST_FAIL_UPLOAD")) : -1;
     hipDeviceProp_t prop;
     PRT_HIP(hipGetDeviceProperties(&prop, device));
     s->n_cu = prop.multiProcessorCount;
@@ -391,7 +419,6 @@ static int upload_impl(PrtScene* s, int device) {
         DTri& a = dt[i];
         std::memcpy(a.n, T.normal, 24);
         a.D = T.D;
-#if PRT_TRI_FORM == 1
         a.A[0] = T.e1[1] * T.w[2] - T.w[1] * T.e1[2]; // e1 x w
         a.A[1] = T.e1[2] * T.w[0] - T.w[2] * T.e1[0];
         a.A[2] = T.e1[0] * T.w[1] - T.w[0] * T.e1[1];
@@ -400,12 +427,6 @@ static int upload_impl(PrtScene* s, int device) {
         a.B[2] = T.w[0] * T.e0[1] - T.e0[0] * T.w[1];
         a.a0 = T.v[0][0] * a.A[0] + T.v[0][1] * a.A[1] + T.v[0][2] * a.A[2];
         a.b0 = T.v[0][0] * a.B[0] + T.v[0][1] * a.B[1] + T.v[0][2] * a.B[2];
-#else
-        std::memcpy(a.w, T.w, 24);
-        std::memcpy(a.v0, T.v[0], 24);
-        std::memcpy(a.e0, T.e0, 24);
-        std::memcpy(a.e1, T.e1, 24);
-#endif
         DTriShade& b = ds[i];
         std::memset(&b, 0, sizeof(b));
         std::memcpy(b.tangent, T.tangent, 24);
@@ -420,7 +441,7 @@ static int upload_impl(PrtScene* s, int device) {
     int rc;
     // packed records for scenes the caches hold, one record per 128-byte line for scenes that stream from HBM
     uint32_t stride = (uint64_t)n * sizeof(DTri) > PRT_TRI_PADDED_ABOVE ? 128u : (uint32_t)sizeof(DTri);
-    if (const char* e = std::getenv("PRT_TUNE_TRI_STRIDE")) stride = std::atoi(e) == 128 ? 128u : (uint32_t)sizeof(DTri);
+    if (const char* e = dev_env("PRT_TUNE_TRI_STRIDE")) stride = std::atoi(e) == 128 ? 128u : (uint32_t)sizeof(DTri);
     if (sizeof(DTri) > 96) stride = (uint32_t)sizeof(DTri);
     d.tri_stride = stride;
     auto up_tris = [&](const DTri** out) -> int { // host records (packed) -> device records `stride` bytes apart
@@ -451,7 +472,7 @@ static int upload_impl(PrtScene* s, int device) {
         if (!prt::build_bvh_device(pb.data(), n, db, &err)) return fail(PRT_E_HIP, "prt_scene_upload: " + err);
         s->allocs.push_back(db.d_nodes);
         d.nodes = db.d_nodes;
-        if (std::getenv("PRT_VALIDATE_BVH")) { // tests: check the device-built tree on the host before any ray visits it
+        if (dev_env("PRT_VALIDATE_BVH")) { // tests: check the device-built tree on the host before any ray visits it
             std::vector<DNode> hn(db.n_nodes);
             PRT_HIP(hipMemcpy(hn.data(), db.d_nodes, (size_t)db.n_nodes * sizeof(DNode), hipMemcpyDeviceToHost));
             if (!prt::validate_nodes(hn.data(), hn.size(), n, &err)) {
@@ -510,21 +531,56 @@ static int upload_impl(PrtScene* s, int device) {
     if ((rc = s->up(s->mats, &d.materials))) return rc;
     {
         // textures go up as bilinear footprints (prt_device.h, tex_value): per cell (x0, y0) the four taps of a lookup, 16 reals
+        // Device layout of the texels, per texture (DTexture::has_data): 1 = BILINEAR FOOTPRINTS — per texel cell the four
+        // taps Value() blends, 16 reals = one 128-byte line per lookup (bathroom2 -1.8 %) at 5.3x the bytes; 2 = the plain
+        // row-major texel array (3 reals per texel, a lookup touches two to four lines).  Footprints are given out smallest
+        // texture first while the scene's footprint bytes stay within PRT_TEX_FOOTPRINT_BUDGET (256 MiB of fp64 records —
+        // the size of the Infinity Cache; the fp32 fast mode adds half as much again when it is used); what does not fit
+        // stays compact: a 4096^2 texture is 403 MB instead of 2.1 GB.  Same doubles, same blend, either way.
         std::vector<DTexture> qt(s->texs);
         std::vector<double> quads;
-        try {
-            size_t cells = 0;
-            for (const DTexture& t : s->texs) cells += t.has_data ? (size_t)t.width * t.height : 0;
-            quads.assign(cells * 16, 0.0);
-        } catch (const std::bad_alloc&) {
-            return fail(PRT_E_OOM, "prt_scene_upload: out of host memory for the texture footprints");
+        std::vector<size_t> order;
+        for (size_t i = 0; i < s->texs.size(); ++i)
+            if (s->texs[i].has_data) order.push_back(i);
+        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+            const size_t cx = (size_t)s->texs[x].width * s->texs[x].height, cy = (size_t)s->texs[y].width * s->texs[y].height;
+            return cx != cy ? cx < cy : x < y;
+        });
+        size_t budget = PRT_TEX_FOOTPRINT_BUDGET;
+        if (const char* e = dev_env("PRT_TUNE_TEX_BUDGET")) budget = (size_t)std::strtoull(e, nullptr, 10);
+        size_t fp_bytes = 0;
+        for (size_t i : order) {
+            const size_t cells = (size_t)s->texs[i].width * s->texs[i].height;
+            const bool footprint = fp_bytes + cells * 16 * sizeof(double) <= budget;
+            qt[i].has_data = footprint ? 1 : 2;
+            if (footprint) fp_bytes += cells * 16 * sizeof(double);
         }
-        size_t at = 0;
+        size_t reals = 0; // footprint records are read as 4-real vectors: they start on a multiple of 16 reals
+        for (size_t i = 0; i < s->texs.size(); ++i) {
+            if (!s->texs[i].has_data) continue;
+            const size_t cells = (size_t)s->texs[i].width * s->texs[i].height;
+            if (qt[i].has_data == 1) reals = (reals + 15) / 16 * 16;
+            qt[i].offset = reals;
+            reals += cells * (qt[i].has_data == 1 ? 16 : 3);
+        }
+        try {
+            quads.assign(reals, 0.0);
+        } catch (const std::bad_alloc&) {
+            return fail(PRT_E_OOM, "prt_scene_upload: out of host memory for the texel arrays");
+        }
         for (size_t i = 0; i < s->texs.size(); ++i) {
             const DTexture& t = s->texs[i];
-            qt[i].offset = at;
-            if (!t.has_data) continue;
+            if (!t.has_data) {
+                qt[i].offset = 0;
+                continue;
+            }
+            size_t at = qt[i].offset;
             const double* px = s->texels_lin.data() + t.offset;
+            if (qt[i].has_data == 2) {
+                const size_t n3 = (size_t)t.width * t.height * 3;
+                std::memcpy(quads.data() + at, px, n3 * sizeof(double));
+                continue;
+            }
             for (int y0 = 0; y0 < t.height; ++y0)
                 for (int x0 = 0; x0 < t.width; ++x0) {
                     const int x1 = std::min(x0 + 1, t.width - 1), y1 = std::min(y0 + 1, t.height - 1); // Texture.cpp:35-36
@@ -534,11 +590,16 @@ static int upload_impl(PrtScene* s, int device) {
                     at += 16;
                 }
         }
+        s->tex_footprint_bytes = fp_bytes;
+        s->tex_layouts = 0;
+        for (const DTexture& t : qt) s->tex_layouts |= t.has_data == 1 ? 1u : t.has_data == 2 ? 2u : 0u;
         s->n_texel_reals = quads.size();
         if ((rc = s->up(qt, &d.textures))) return rc;
         if ((rc = s->up(quads, &d.texels_lin))) return rc;
     }
     if ((rc = s->up(s->lights.nodes, &d.light_nodes))) return rc;
+    d.light_tab = nullptr;
+    if (!s->lights.tab.empty() && (rc = s->up(s->lights.tab, &d.light_tab))) return rc;
     if ((rc = s->up(s->lights.tris, &d.light_tris))) return rc;
     d.light_root = s->lights.root;
     d.n_lights = (int32_t)s->lights.tris.size();
@@ -550,14 +611,12 @@ static int upload_impl(PrtScene* s, int device) {
         d.grid_origin[a] = s->bvh.grid_origin[a];
         d.grid_step[a] = s->bvh.grid_step[a];
     }
-#if PRT_NODE16
     {
         // box coordinates reach the slab test relative to the grid origin: what bounds its rounding is the grid's extent
         double e = 0.0;
         for (int a = 0; a < 3; ++a) e = std::max(e, 65535.0 * (double)s->bvh.grid_step[a]);
         d.slab_scale = std::nextafter((float)e, std::numeric_limits<float>::infinity());
     }
-#endif
     for (PrtScene::CallSlot& q : s->slots) {
         PRT_HIP(hipMalloc(reinterpret_cast<void**>(&q.d_ctr), sizeof(DCounters)));
         PRT_HIP(hipMemset(q.d_ctr, 0, sizeof(DCounters)));
@@ -571,7 +630,7 @@ static int upload_impl(PrtScene* s, int device) {
         if (m.type == PRT_MAT_PHONG) s->feat |= 2;
         if (m.type == PRT_MAT_COOKTORRANCE) s->feat |= 4;
     }
-    if (const char* e = std::getenv("PRT_TUNE_FEAT")) s->feat |= std::atoi(e); // developer: force a larger permutation
+    if (const char* e = dev_env("PRT_TUNE_FEAT")) s->feat |= std::atoi(e); // developer: force a larger permutation
     s->feat = prt::render_permutation(s->feat);
     // Small read-only tables of the shading code live in LDS (LLDS kernels): every read of them is otherwise a
     // texture-addresser instruction, and the light tree's descent is a chain of dependent reads.  In order of
@@ -591,21 +650,12 @@ static int upload_impl(PrtScene* s, int device) {
         s->d_k3 = d;
         s->d_nodes_shallow = nullptr;
         s->n_nodes_shallow = 0;
-        const int full_depth = PRT_STACK_DEPTH; // the fp64 render kernels keep static stacks of the builders' bound (a run-time depth cost them 1.2 %)
-        const bool tables_fit = prt::render_lds_budget(s->feat, full_depth) >= (int)(s->mats.size() * sizeof(DMaterial));
-        if (!tables_fit && s->stack_need > PRT_STACK_SHALLOW && !s->bvh_info.built_on_device && !s->bvh.nodes_shallow.empty()) {
-            // A deep tree whose stacks would leave a block no LDS for its shading tables at the kernel's occupancy: the host
-            // builder kept the same binary tree collapsed for 32 entries (same leaves, same triangle order, ~0.1 % more
-            // nodes, +2 % frame time on bathroom2).  K3 traverses that one then — losing a resident block costs far more
-            // (measured: 71.9 ms vs 47.8 ms per bathroom2 frame at two blocks per CU).  K1 keeps the wider tree.
-            if ((rc = s->up(s->bvh.nodes_shallow, &s->d_nodes_shallow))) return rc;
-            s->n_nodes_shallow = (uint32_t)s->bvh.nodes_shallow.size();
-            s->d_k3.nodes = s->d_nodes_shallow;
-            s->d_k3.n_nodes = s->n_nodes_shallow;
-            s->stack_need = std::min(s->stack_need, PRT_STACK_SHALLOW);
-        }
-        s->stack_depth = s->d_nodes_shallow ? PRT_STACK_SHALLOW : PRT_STACK_DEPTH;
-        if (std::getenv("PRT_TUNE_VERBOSE")) std::fprintf(stderr, "[prt] tree needs %d stack entries\n", s->stack_need);
+        // The fp64 render kernels keep STATIC stacks of PRT_STACK_DEPTH entries per lane (they are register-limited to three
+        // blocks per CU; a run-time depth cost them 1.2 %), so a shallower collapse of the tree frees them no LDS: they
+        // always traverse the full tree, and their table budget is what those static stacks leave.  (The fp32 kernels size
+        // their stacks per launch and do take the 32-entry collapse of a deep host-built tree: upload_f32_tables.)
+        s->stack_depth = PRT_STACK_DEPTH;
+        if (dev_env("PRT_TUNE_VERBOSE")) std::fprintf(stderr, "[prt] tree needs %d stack entries\n", s->stack_need);
     }
     size_tables(s, prt::render_lds_budget(s->feat, s->stack_depth), sizeof(DMaterial), sizeof(DLightTri), sizeof(DLightNode),
                 &s->mat_lds, &s->ltri_lds, &s->light_lds);
@@ -613,8 +663,16 @@ static int upload_impl(PrtScene* s, int device) {
     const size_t tables = prt::render_table_bytes(s->light_lds, s->mat_lds, s->ltri_lds);
     const bool pad = d.tri_stride == PRT_TRI_PAD_STRIDE(double) && sizeof(DTri) != PRT_TRI_PAD_STRIDE(double);
     s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat, tables, s->stack_depth, pad);
-    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, tables, s->stack_depth, pad);
-    if (std::getenv("PRT_TUNE_VERBOSE"))
+    s->blocks_wanted = tables != 0 ? prt::render_blocks_per_cu(false, s->feat, 0, s->stack_depth, pad) : s->blocks_per_cu[0];
+    if (s->blocks_per_cu[0] < s->blocks_wanted) {
+        // the tables would cost the production kernel a resident block (the budget is an estimate; the occupancy query is
+        // the truth): a block per CU is worth far more than the tables — render without them
+        s->mat_lds = s->ltri_lds = s->light_lds = 0;
+        s->blocks_per_cu[0] = s->blocks_wanted;
+    }
+    const size_t tables_used = prt::render_table_bytes(s->light_lds, s->mat_lds, s->ltri_lds);
+    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, tables_used, s->stack_depth, pad);
+    if (dev_env("PRT_TUNE_VERBOSE"))
         std::fprintf(stderr, "[prt] fp64 render kernels: %d blocks per CU, LDS tables: %d materials, %d light triangles, %d light nodes\n",
                      s->blocks_per_cu[0], s->mat_lds, s->ltri_lds, s->light_lds);
     return PRT_OK;
@@ -733,6 +791,7 @@ static int ensure_f32_impl(PrtScene* s) {
     f.textures = d.textures;
     f.texels_lin = static_cast<const float*>(tx);
     f.light_root = d.light_root;
+    f.light_tab = d.light_tab; // thresholds are floats in either mode
     f.n_lights = d.n_lights;
     f.light_area = (float)d.light_area;
     f.n_nodes = d.n_nodes;
@@ -764,8 +823,8 @@ static int ensure_f32_impl(PrtScene* s) {
             need = std::min(need, PRT_STACK_SHALLOW);
         }
         s->stack_depth32 = need <= PRT_STACK_SHALLOW ? PRT_STACK_SHALLOW : PRT_STACK_DEPTH;
-        if (const char* e = std::getenv("PRT_TUNE_STACK32")) s->stack_depth32 = std::max(need, std::min(PRT_STACK_DEPTH, std::atoi(e))); // developer: smaller stacks when the tree allows
-        if (std::getenv("PRT_TUNE_VERBOSE")) std::fprintf(stderr, "[prt] fp32 tables: tree needs %d stack entries, using %d\n", need, s->stack_depth32);
+        if (const char* e = dev_env("PRT_TUNE_STACK32")) s->stack_depth32 = std::max(need, std::min(PRT_STACK_DEPTH, std::atoi(e))); // developer: smaller stacks when the tree allows
+        if (dev_env("PRT_TUNE_VERBOSE")) std::fprintf(stderr, "[prt] fp32 tables: tree needs %d stack entries, using %d\n", need, s->stack_depth32);
     }
     size_tables(s, prt32::render_lds_budget(s->feat, s->stack_depth32), sizeof(DMaterialT<float>), sizeof(DLightTriT<float>),
                 sizeof(DLightNodeT<float>), &s->mat_lds32, &s->ltri_lds32, &s->light_lds32);
@@ -773,7 +832,7 @@ static int ensure_f32_impl(PrtScene* s) {
     const bool pad = stride == PRT_TRI_PAD_STRIDE(float) && sizeof(DTriT<float>) != PRT_TRI_PAD_STRIDE(float);
     s->blocks_per_cu32[0] = prt32::render_blocks_per_cu(false, s->feat, tables, s->stack_depth32, pad);
     s->blocks_per_cu32[1] = prt32::render_blocks_per_cu(true, s->feat, tables, s->stack_depth32, pad);
-    if (std::getenv("PRT_TUNE_VERBOSE"))
+    if (dev_env("PRT_TUNE_VERBOSE"))
         std::fprintf(stderr, "[prt] fp32 render kernels: %d blocks per CU, stacks %d, LDS tables: %d materials, %d light triangles, %d light nodes\n",
                      s->blocks_per_cu32[0], s->stack_depth32, s->mat_lds32, s->ltri_lds32, s->light_lds32);
     s->f32_ready = true;
@@ -1016,11 +1075,11 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.leaf_batch = s->feat == 0 ? 48 : 40;
     P.inner_min = s->feat == 0 ? 20 : 12;
     P.cached_min = 24; // measured: veach-mis -1 %, the others flat
-    if (const char* e = std::getenv("PRT_TUNE_CACHED_MIN")) P.cached_min = std::atoi(e);
-    if (const char* e = std::getenv("PRT_TUNE_KEEP")) P.keep = std::atoi(e);
-    if (const char* e = std::getenv("PRT_TUNE_LEAF_BATCH")) P.leaf_batch = std::atoi(e);
-    if (const char* e = std::getenv("PRT_TUNE_INNER_MIN")) P.inner_min = std::atoi(e);
-    if (const char* e = std::getenv("PRT_TUNE_SCRAMBLE")) P.scramble = std::atoi(e); // experiment: incoherent pixel order
+    if (const char* e = dev_env("PRT_TUNE_CACHED_MIN")) P.cached_min = std::max(1, std::atoi(e)); // (0 would keep a wave passing for ever)
+    if (const char* e = dev_env("PRT_TUNE_KEEP")) P.keep = std::atoi(e);
+    if (const char* e = dev_env("PRT_TUNE_LEAF_BATCH")) P.leaf_batch = std::atoi(e);
+    if (const char* e = dev_env("PRT_TUNE_INNER_MIN")) P.inner_min = std::atoi(e);
+    if (const char* e = dev_env("PRT_TUNE_SCRAMBLE")) P.scramble = std::atoi(e) ? 1 : 0; // experiment: incoherent pixel order (PRT_ITEMS_FROM_LIST stays internal to prt_render_samples)
     for (int c = 0; c < 3; ++c) P.background[c] = p->background[c];
     P.seed_key = prt::seed_key(p->seed); // the seed is hashed on its own, once per launch (prt_device.h, Rng)
     int tile = p->tile_size > 0 ? p->tile_size : 32;
@@ -1056,7 +1115,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     std::vector<int> sizes;
     const int spp = p->spp;
     int want = p->sample_chunks;
-    if (const char* e = std::getenv("PRT_TUNE_CHUNKS")) want = std::atoi(e);
+    if (const char* e = dev_env("PRT_TUNE_CHUNKS")) want = std::atoi(e);
     if (want > 0) {
         want = std::min(want, std::min(spp, PRT_MAX_CHUNKS));
         for (int c = 0; c < want; ++c) sizes.push_back((int)(((int64_t)(c + 1) * spp) / want - ((int64_t)c * spp) / want));
@@ -1066,10 +1125,10 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
         // largest item: beyond ~100 samples the per-item costs are already amortised; a small tile share (fewer owned
         // pixels than resident lanes x 2) does 1 % better with 64 (53.1 -> 52.6 ms on a 1/8 share of the cornell frame)
         int body = P.items_per_chunk < 2 * lanes ? 64 : 128;
-        if (const char* e = std::getenv("PRT_TUNE_BODY")) body = std::max(1, std::atoi(e));
+        if (const char* e = dev_env("PRT_TUNE_BODY")) body = std::max(1, std::atoi(e));
         body = std::max(body, (spp + PRT_MAX_CHUNKS / 2 - 1) / (PRT_MAX_CHUNKS / 2)); // very high spp: the body must fit in half the table
         double var = 4.0; // measured optimum with the multi-queue item dealing (3 before it: short items were fetch-bound)
-        if (const char* e = std::getenv("PRT_TUNE_VAR")) var = std::max(0.25, std::atof(e));
+        if (const char* e = dev_env("PRT_TUNE_VAR")) var = std::max(0.25, std::atof(e));
         double c = ((double)P.items_per_chunk / (double)lanes) / var;
         for (;;) {
             sizes.clear();
@@ -1121,7 +1180,7 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
         const uint64_t want = (P.n_items + PRT_BLOCK - 1) / PRT_BLOCK;
         const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(want, (uint64_t)s->n_cu * bpc));
         if ((rc = set_slot_pointers(s, q, st, grid, nullptr, nullptr))) return rc;
-        if (const char* e = std::getenv("PRT_TUNE_DUMP_RAYS")) { // "<max rays>,<file>" (counting launches only)
+        if (const char* e = dev_env("PRT_TUNE_DUMP_RAYS")) { // "<max rays>,<file>" (counting launches only)
             const std::string v(e);
             const size_t comma = v.find(',');
             if (count && comma != std::string::npos) {
@@ -1325,11 +1384,20 @@ std::mutex g_comm_mutex;
 std::map<std::vector<int>, CommSet> g_comms;
 } // namespace
 
-// Camera::Render over several GPUs of this process (prt.h).  Single host thread: every device's launches are
-// asynchronous; the reduce is one grouped RCCL call.
-int prt_render_multi(PrtScene* const* scenes, int n, const PrtCamera* cam, const PrtRenderParams* p, float* rgb_f32) {
-    if (!scenes || n < 1 || !cam || !p || !rgb_f32) return fail(PRT_E_INVALID, "prt_render_multi: null argument");
-    if (cam->width < 1 || cam->height < 1) return fail(PRT_E_INVALID, "prt_render_multi: bad image size");
+namespace {
+// Restores the caller's current HIP device on every way out of a call that visits several devices.
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+void drop_comms_locked(std::map<std::vector<int>, CommSet>::iterator it, bool abort) {
+    for (ncclComm_t c : it->second.comms)
+        if (c) (void)(abort ? ncclCommAbort(c) : ncclCommDestroy(c));
+    g_comms.erase(it);
+}
+
+int render_multi_impl(PrtScene* const* scenes, int n, const PrtCamera* cam, const PrtRenderParams* p, float* rgb_f32) {
     std::vector<int> devs(n);
     for (int r = 0; r < n; ++r) {
         if (!scenes[r]) return fail(PRT_E_INVALID, "prt_render_multi: null scene");
@@ -1365,9 +1433,11 @@ int prt_render_multi(PrtScene* const* scenes, int n, const PrtCamera* cam, const
         const int rc = prt_render_device(s, cam, &pr, nullptr, s->multi_fb, 0, nullptr);
         if (rc != PRT_OK) return rc;
     }
-    // test hook: a single scene goes through the RCCL branch as well (a communicator of one rank) — the most of that branch
-    // a one-GPU box can execute: library, communicator, the grouped reduce on the device buffer, the stream order
-    const bool force_rccl = n == 1 && std::getenv("PRT_TEST_FORCE_RCCL") && std::atoi(std::getenv("PRT_TEST_FORCE_RCCL"));
+    // test hooks (PRT_DEV_HOOKS builds only).  PRT_TEST_FORCE_RCCL: a single scene goes through the RCCL branch as well (a
+    // communicator of one rank) — the most of that branch a one-GPU box can execute: library, communicator, the grouped
+    // reduce on the device buffer, the stream order.  PRT_TEST_FAIL_NCCL=init|reduce: that step reports a failure.
+    const bool force_rccl = n == 1 && dev_env("PRT_TEST_FORCE_RCCL") && std::atoi(dev_env("PRT_TEST_FORCE_RCCL"));
+    const char* inject = dev_env("PRT_TEST_FAIL_NCCL");
     if (n > 1 && all_same) {
         // tile shares of one device (replicas; a rehearsal of the multi-GPU path on one GPU): summed where they are
         PRT_HIP(hipSetDevice(devs[0]));
@@ -1375,30 +1445,44 @@ int prt_render_multi(PrtScene* const* scenes, int n, const PrtCamera* cam, const
         PRT_HIP(hipGetLastError());
     } else if (n > 1 || force_rccl) {
         // ONE collective: reduce(sum) of the fp32 framebuffers to the first device over RCCL (xGMI between the GPUs of a
-        // node).  Tiles are disjoint, so every element is x + 0 + ... + 0: the result is the single-GPU image bit for bit.
-        CommSet* cs = nullptr;
-        {
-            std::lock_guard<std::mutex> lock(g_comm_mutex);
-            auto it = g_comms.find(devs);
-            if (it == g_comms.end()) {
-                CommSet fresh;
-                fresh.comms.resize(n);
-                const ncclResult_t nr = ncclCommInitAll(fresh.comms.data(), n, devs.data());
-                if (nr != ncclSuccess)
-                    return fail(PRT_E_HIP, std::string("prt_render_multi: ncclCommInitAll failed: ") + ncclGetErrorString(nr) +
-                                               " (no host-side fallback exists: the frame is not assembled)");
-                it = g_comms.emplace(devs, std::move(fresh)).first;
+        // node).  Tiles are disjoint, so every element is x + 0 + ... + 0: the reduce is exact.  The communicator set of a
+        // device list is created once and kept (prt_shutdown destroys them); the mutex is held for the whole collective,
+        // so two host threads cannot interleave grouped calls on the same communicators.
+        std::lock_guard<std::mutex> lock(g_comm_mutex);
+        auto it = g_comms.find(devs);
+        if (it == g_comms.end()) {
+            CommSet fresh;
+            fresh.comms.assign(n, nullptr);
+            ncclResult_t nr = (inject && !std::strcmp(inject, "init")) ? ncclSystemError : ncclCommInitAll(fresh.comms.data(), n, devs.data());
+            if (nr != ncclSuccess) {
+                for (ncclComm_t c : fresh.comms) // whatever a failed initialisation left behind
+                    if (c) (void)ncclCommAbort(c);
+                return fail(PRT_E_HIP, std::string("prt_render_multi: ncclCommInitAll failed: ") + ncclGetErrorString(nr) +
+                                           " (no host-side fallback exists: the frame is not assembled)");
             }
-            cs = &it->second;
+            it = g_comms.emplace(devs, std::move(fresh)).first;
         }
+        CommSet& cs = it->second;
+        // Every error between ncclGroupStart and ncclGroupEnd is COLLECTED: the group is always closed before the call fails.
+        std::string what;
         ncclResult_t nr = ncclGroupStart();
+        if (nr != ncclSuccess) return fail(PRT_E_HIP, std::string("prt_render_multi: ncclGroupStart failed: ") + ncclGetErrorString(nr));
         for (int r = 0; r < n && nr == ncclSuccess; ++r) {
-            PRT_HIP(hipSetDevice(devs[r]));
-            nr = ncclReduce(scenes[r]->multi_fb, scenes[r]->multi_fb, npx, ncclFloat, ncclSum, 0, cs->comms[r], nullptr);
+            const hipError_t he = hipSetDevice(devs[r]);
+            if (he != hipSuccess) {
+                what = std::string("hipSetDevice: ") + hipGetErrorString(he);
+                nr = ncclUnhandledCudaError;
+                break;
+            }
+            nr = (inject && !std::strcmp(inject, "reduce")) ? ncclInternalError
+                 : ncclReduce(scenes[r]->multi_fb, scenes[r]->multi_fb, npx, ncclFloat, ncclSum, 0, cs.comms[r], nullptr);
         }
         const ncclResult_t ne = ncclGroupEnd();
         if (nr == ncclSuccess) nr = ne;
-        if (nr != ncclSuccess) return fail(PRT_E_HIP, std::string("prt_render_multi: ncclReduce failed: ") + ncclGetErrorString(nr));
+        if (nr != ncclSuccess) {
+            drop_comms_locked(it, true); // a communicator that failed a collective is not used again
+            return fail(PRT_E_HIP, std::string("prt_render_multi: ncclReduce failed: ") + ncclGetErrorString(nr) + (what.empty() ? "" : " (" + what + ")"));
+        }
         for (int r = 1; r < n; ++r) { // the root's copy below only waits for the root's stream
             PRT_HIP(hipSetDevice(devs[r]));
             PRT_HIP(hipDeviceSynchronize());
@@ -1408,6 +1492,27 @@ int prt_render_multi(PrtScene* const* scenes, int n, const PrtCamera* cam, const
     PRT_HIP(hipDeviceSynchronize());
     PRT_HIP(hipMemcpy(rgb_f32, scenes[0]->multi_fb, npx * sizeof(float), hipMemcpyDeviceToHost));
     return PRT_OK;
+}
+} // namespace
+
+// Camera::Render over several GPUs of this process (prt.h).  Single host thread: every device's launches are
+// asynchronous; the reduce is one grouped RCCL call.  The caller's current device is restored on every way out.
+// EXPERIMENTAL for n > 1 on different devices: that branch has only ever run with a one-rank communicator (rounds 1-4
+// had one-GPU boxes); the result is an fp32 framebuffer (the reduce's element type), not the fp64 one of prt_render.
+int prt_render_multi(PrtScene* const* scenes, int n, const PrtCamera* cam, const PrtRenderParams* p, float* rgb_f32) {
+    if (!scenes || n < 1 || !cam || !p || !rgb_f32) return fail(PRT_E_INVALID, "prt_render_multi: null argument");
+    if (cam->width < 1 || cam->height < 1) return fail(PRT_E_INVALID, "prt_render_multi: bad image size");
+    DeviceGuard guard;
+    return render_multi_impl(scenes, n, cam, p, rgb_f32);
+}
+
+// Releases what the library keeps for the whole process: the cached RCCL communicators of prt_render_multi.  Scenes are
+// not touched (prt_scene_destroy).  Call it before the process exits when prt_render_multi ran over several devices; safe
+// to call any number of times, and prt_render_multi creates communicators again when it needs them.
+void prt_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_comm_mutex);
+    DeviceGuard guard;
+    while (!g_comms.empty()) drop_comms_locked(g_comms.begin(), false);
 }
 
 int prt_get_counters(PrtScene* s, PrtCounters* out) {

@@ -1,7 +1,7 @@
 // prt_device.h — device functions of the gfx950 path tracer (wave64, fp64 arithmetic).
 //
 // Everything here is written for CDNA4 directly: per-lane traversal of a 4-wide BVH (64-byte nodes: four children's
-// boxes on a 16-bit grid; PRT_BVH_WIDTH 2 keeps the 32-byte binary node for A/B) with a lane-strided LDS stack
+// boxes on a 16-bit grid) with a lane-strided LDS stack
 // (conflict-free: entry e of lane l lives at word e*64+l), 96-byte fp64 triangle records (plane + two edge functions;
 // 48 bytes in the fp32 translation unit), shading in the scalar type of the translation unit.
 //
@@ -24,24 +24,6 @@ template <> struct real4_of<double> { typedef double4 type; };
 template <> struct real4_of<float> { typedef float4 type; };
 typedef real4_of<real>::type real4;
 #define PRT_NOCUR ((int32_t)0x80000000) // Trav::cur sentinel (never a valid leaf ref: n_tris < 2^28)
-#ifndef PRT_PREFETCH_TOP
-#define PRT_PREFETCH_TOP 0 // request the stack's top entry at push time: measured 5-12 % SLOWER on every workload — kept as the A/B switch
-#endif
-#ifndef PRT_DEFER_LEAF
-#define PRT_DEFER_LEAF 0 // speculative leaf deferral: better lane utilisation (node rounds 51%->55%) but 3-5% slower (more triangle tests, heavier leaf rounds) on MI355X
-#endif
-#ifndef PRT_TRI_EAGER
-#define PRT_TRI_EAGER 0 // 1: request all 128 bytes of a triangle before its plane test (measured -3 %: the texture addresser is the busier unit)
-#endif
-#ifndef PRT_BOX_ROTATE
-#define PRT_BOX_ROTATE (PRT_BVH_WIDTH == 4) // 4-wide nodes: packed ranges rotated by the ray's direction sign instead of min/max per axis
-#endif
-#ifndef PRT_SLOT_CHECK
-#define PRT_SLOT_CHECK 1
-#endif
-#ifndef PRT_GRID_REL
-#define PRT_GRID_REL 1
-#endif
 #ifndef PRT_BOX_PK
 #define PRT_BOX_PK 1 // K3 permutations other than the lean one: the two plane parameters of an axis through one v_pk_fma_f32
 #endif
@@ -74,11 +56,7 @@ PRT_DEV d3 cross(d3 x, d3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * 
 // (v_rsq_f64 / v_rcp_f64, ~2^-23 relative) plus one coupled Newton step and one residual correction — within an ulp
 // or two of the IEEE result (the parity tolerance is 1e-9) in 7-8 instructions instead of the 14-17 of the
 // correctly rounded, range-scaled library sequences.  Arguments are positive normal numbers wherever these are
-// used (squared lengths, pdfs, |direction components|); zero is handled, NaN propagates.  PRT_FAST_F64=0: IEEE.
-#ifndef PRT_FAST_F64
-#define PRT_FAST_F64 1
-#endif
-#if PRT_FAST_F64
+// used (squared lengths, pdfs, |direction components|); zero is handled, NaN propagates.
 PRT_DEV double fast_rsqrt(double x) { // 1 / sqrt(x), x > 0
     const double y = __builtin_amdgcn_rsq(x);
     const double g = x * y, h = 0.5 * y;
@@ -107,12 +85,6 @@ PRT_DEV double fast_div(double a, double b) { // a / b, b != 0
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
 }
-#else
-PRT_DEV double fast_rsqrt(double x) { return 1.0 / sqrt(x); }
-PRT_DEV double fast_sqrt(double x) { return sqrt(x); }
-PRT_DEV double fast_rcp(double b) { return 1.0 / b; }
-PRT_DEV double fast_div(double a, double b) { return a / b; }
-#endif
 // fp32 fast mode: the hardware instructions themselves (v_rsq_f32 / v_sqrt_f32 / v_rcp_f32, 1 ulp) — one instruction each
 PRT_DEV float fast_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 PRT_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -204,8 +176,8 @@ PRT_DEV const DTri* tri_at(const DScene& S, uint32_t i) {
     return reinterpret_cast<const DTri*>(reinterpret_cast<const char*>(S.tris) + (size_t)i * (PAD ? PRT_TRI_PAD_STRIDE(real) : (uint32_t)sizeof(DTri)));
 }
 
-// Triangle::Hit + IsInterior (Triangle.cpp:54-83,100-113), inclusive interval.  PRT_TRI_FORM 0: the reference's
-// expressions; 1: the same quantities through precomputed edge functions (see DTri).
+// Triangle::Hit + IsInterior (Triangle.cpp:54-83,100-113), inclusive interval: the reference's quantities through
+// precomputed edge functions (see DTri).
 PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, real tmin, real tmax, real& t_out, real& a_out,
                       real& b_out, const real4* pre = nullptr, uint32_t* n_full = nullptr) {
     const real4* q = reinterpret_cast<const real4*>(T);
@@ -214,40 +186,12 @@ PRT_DEV bool tri_test(const DTri* __restrict__ T, d3 o, d3 d, real tmin, real tm
     real denom = dot(n, d);
     if (fabs(denom) < RL(1e-8)) return false;
     real t = ieee_div(q0.w - dot(n, o), denom);
-#if PRT_TRI_FORM == 1
     if (!(tmin <= t && t <= tmax)) return false;
     if (n_full) ++*n_full;
-    {
-        const real4 q2 = q[2];
-        const d3 p = o + d * t;
-        const real alpha = (p.x * q1.x + p.y * q1.y + p.z * q1.z) - q1.w;
-        const real beta = (p.x * q2.x + p.y * q2.y + p.z * q2.z) - q2.w;
-        if (alpha != alpha || beta != beta) return false;
-        if ((alpha < 0) || (beta < 0) || (alpha + beta > 1)) return false;
-        t_out = t;
-        a_out = alpha;
-        b_out = beta;
-        return true;
-    }
-#endif
-#if PRT_TRI_EAGER
-    real4 q2 = q[2], q3 = q[3]; // whole record requested up front: one memory latency per test instead of two
-    asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w), "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w)); // keeps the loads above the branch
-#endif
-    if (!(tmin <= t && t <= tmax)) return false;
-    if (n_full) ++*n_full;
-    // record = n[3] D | w[3] v0.x | v0.yz e0.xy | e0.z e1[3]
-#if !PRT_TRI_EAGER
-    real4 q2 = q[2], q3 = q[3];
-#endif
-    d3 w = mk3(q1.x, q1.y, q1.z);
-    d3 v0 = mk3(q1.w, q2.x, q2.y);
-    d3 e0 = mk3(q2.z, q2.w, q3.x);
-    d3 e1 = mk3(q3.y, q3.z, q3.w);
-    d3 p = o + d * t;
-    d3 v0p = p - v0;
-    real alpha = dot(w, cross(v0p, e1));
-    real beta = dot(w, cross(e0, v0p));
+    const real4 q2 = q[2];
+    const d3 p = o + d * t;
+    const real alpha = (p.x * q1.x + p.y * q1.y + p.z * q1.z) - q1.w;
+    const real beta = (p.x * q2.x + p.y * q2.y + p.z * q2.z) - q2.w;
     if (alpha != alpha || beta != beta) return false;
     if ((alpha < 0) || (beta < 0) || (alpha + beta > 1)) return false;
     t_out = t;
@@ -277,32 +221,21 @@ PRT_DEV float f32_down(real x) {
 // clamped to 1e28 so a zero direction component never yields inf - inf.
 struct SlabAxis {
     float idq, c_lo, c_hi;
-#if PRT_BOX_ROTATE
     uint32_t rot; // 16 when the ray runs against this axis: the packed (lo | hi << 16) range is rotated so that its
                   // low half is always the ENTRY plane and c_lo / c_hi are the entry / exit constants
-#endif
 };
 PRT_DEV SlabAxis slab_axis(real o, real d, float E, float g0, float gs) {
     SlabAxis a;
     const float df = (float)d;
     float id = __builtin_amdgcn_rcpf(df);
     if (!(fabsf(id) <= 1e28f)) id = copysignf(1e28f, df);
-#if PRT_GRID_REL
     const float r = (float)((real)g0 - o);
-#else
-    const float r = g0 - (float)o;
-#endif
     const float c = r * id;
     const float pad = fmaf(E, fabsf(id), fabsf(c)) * 9.5367432e-7f; // (|r| + E) * |id| * 2^-20 with |c| = |r| |id|
     a.idq = gs * id;
-#if PRT_BOX_ROTATE
     a.c_lo = c - pad; // entry plane
     a.c_hi = c + pad; // exit plane
     a.rot = id >= 0.f ? 0u : 16u;
-#else
-    a.c_lo = id >= 0.f ? c - pad : c + pad; // the lo plane is the entry plane when id >= 0
-    a.c_hi = id >= 0.f ? c + pad : c - pad;
-#endif
     return a;
 }
 
@@ -325,13 +258,9 @@ struct Trav {
     HitInfo hit;
     SlabAxis ax, ay, az;
     float tminf, tbestf;
-    int32_t cur;  // >= 0 inner node, < 0 leaf ref, PRT_NOCUR = nothing to visit until the pending leaf is tested
-    int32_t pend; // 0 = none, else a leaf ref reached earlier whose triangles are still to be tested
+    int32_t cur;  // >= 0 inner node, < 0 leaf ref (the lane is parked there until the wave's next leaf round)
     int32_t sp;
     bool active;
-#if PRT_PREFETCH_TOP
-    uint32_t pf = 0; // destination of the prefetch of the stack's top entry (never read)
-#endif
 
     PRT_DEV void init(const DScene& S, d3 o_, d3 d_, real tmin_, real tmax_) {
         o = o_;
@@ -341,29 +270,20 @@ struct Trav {
     // Starts the traversal of the ray already in o / d.
     PRT_DEV void start(const DScene& S, real tmin_, real tmax_) {
         tmin = tmin_;
-#if PRT_NODE16
         ax = slab_axis(o.x, d.x, S.slab_scale, S.grid_origin[0], S.grid_step[0]);
         ay = slab_axis(o.y, d.y, S.slab_scale, S.grid_origin[1], S.grid_step[1]);
         az = slab_axis(o.z, d.z, S.slab_scale, S.grid_origin[2], S.grid_step[2]);
-#else
-        ax = slab_axis(o.x, d.x, S.slab_scale, 0.f, 1.f);
-        ay = slab_axis(o.y, d.y, S.slab_scale, 0.f, 1.f);
-        az = slab_axis(o.z, d.z, S.slab_scale, 0.f, 1.f);
-#endif
         tminf = f32_down(tmin_);
         tbestf = f32_up(tmax_);
         hit.t = tmax_;
         hit.tri = -1;
         sp = 0;
         cur = 0;
-        pend = 0;
         active = S.n_tris != 0;
     }
 
-#if PRT_BVH_WIDTH == 4
     // Entry / exit parameters of one child box: its three packed (lo | hi << 16) grid ranges against the ray's slabs.
     PRT_DEV void box4(uint32_t x, uint32_t y, uint32_t z, float& n, float& f) const {
-#if PRT_BOX_ROTATE
         // no min/max per axis: after the rotation the low half IS the entry plane.  An unused slot (inverted range on
         // every axis) comes out with entry beyond exit for every ray near the scene (see inner_step for the others).
         x = __builtin_amdgcn_alignbit(x, x, ax.rot);
@@ -372,9 +292,8 @@ struct Trav {
         float nx, fx, ny, fy, nz, fz;
         if (PK) {
         // entry and exit plane of an axis in one packed FMA (v_pk_fma_f32: two fp32 FMAs per instruction, 12 instead
-        // of 24 per node visit).  Costs three registers (the splat of each axis's 1/d): measured bathroom2 +1.6 %,
-        // veach-mis +0.9 %, but cornell -1.5 % (the lean kernel sits exactly at its 168-register budget and spills 4)
-        // and K1 -1 % — so K3 uses it for every permutation except the lean one.
+        // of 24 per node visit).  Costs three registers (the splat of each axis's 1/d); no gain in issue slots
+        // (v_pk_fma_f32 is half rate), so it pays only through registers: K3 uses it, K1 (-1 %) does not.
         typedef float f2_ __attribute__((ext_vector_type(2)));
         const f2_ tx = __builtin_elementwise_fma(f2_{(float)(x & 0xffffu), (float)(x >> 16)}, f2_{ax.idq, ax.idq}, f2_{ax.c_lo, ax.c_hi});
         const f2_ ty = __builtin_elementwise_fma(f2_{(float)(y & 0xffffu), (float)(y >> 16)}, f2_{ay.idq, ay.idq}, f2_{ay.c_lo, ay.c_hi});
@@ -387,19 +306,6 @@ struct Trav {
         }
         n = fmaxf(fmaxf(fmaxf(nx, ny), nz), tminf);
         f = fminf(fminf(fminf(fx, fy), fz), tbestf);
-        return;
-#endif
-        float l = fmaf((float)(x & 0xffffu), ax.idq, ax.c_lo), h = fmaf((float)(x >> 16), ax.idq, ax.c_hi);
-        n = fminf(l, h);
-        f = fmaxf(l, h);
-        l = fmaf((float)(y & 0xffffu), ay.idq, ay.c_lo);
-        h = fmaf((float)(y >> 16), ay.idq, ay.c_hi);
-        n = fmaxf(n, fminf(l, h));
-        f = fminf(f, fmaxf(l, h));
-        l = fmaf((float)(z & 0xffffu), az.idq, az.c_lo);
-        h = fmaf((float)(z >> 16), az.idq, az.c_hi);
-        n = fmaxf(fmaxf(n, fminf(l, h)), tminf);
-        f = fminf(fminf(f, fmaxf(l, h)), tbestf);
     }
     // One visit of a 4-wide node: four 16-byte loads (x ranges, y ranges, z ranges, refs), four box tests, the
     // children that are hit sorted by entry distance (5 compare-exchanges on (distance bits, ref) pairs; a miss
@@ -417,7 +323,6 @@ struct Trav {
         box4(bx.w, by.w, bz.w, n3, f3);
         // entry distances are >= tminf; as unsigned integers positive floats order like the floats themselves
         // (a non-positive tmin only costs ordering quality, never correctness)
-#if PRT_BOX_ROTATE
         // Both builders fill a node's slots from the front and every node has at least two children, so only slots 2
         // and 3 can be unused (ref 0x80000000, inverted range).  The inverted range alone does not keep a ray out of
         // them: the pad grows with the ray's distance from the scene, and from ~2^19 scene sizes away it exceeds the
@@ -425,24 +330,8 @@ struct Trav {
         // would lose its stack or never end.  Hence the two explicit checks.
         uint32_t k0 = n0 <= f0 ? __float_as_uint(n0) : 0xffffffffu;
         uint32_t k1 = n1 <= f1 ? __float_as_uint(n1) : 0xffffffffu;
-#if PRT_SLOT_CHECK
         uint32_t k2 = (n2 <= f2 && rf.z != 0x80000000u) ? __float_as_uint(n2) : 0xffffffffu;
         uint32_t k3 = (n3 <= f3 && rf.w != 0x80000000u) ? __float_as_uint(n3) : 0xffffffffu;
-#else
-        uint32_t k2 = n2 <= f2 ? __float_as_uint(n2) : 0xffffffffu;
-        uint32_t k3 = n3 <= f3 ? __float_as_uint(n3) : 0xffffffffu;
-#endif
-#else
-        uint32_t k0 = (n0 <= f0 && rf.x != 0x80000000u) ? __float_as_uint(n0) : 0xffffffffu;
-        uint32_t k1 = (n1 <= f1 && rf.y != 0x80000000u) ? __float_as_uint(n1) : 0xffffffffu;
-#if PRT_SLOT_CHECK
-        uint32_t k2 = (n2 <= f2 && rf.z != 0x80000000u) ? __float_as_uint(n2) : 0xffffffffu;
-        uint32_t k3 = (n3 <= f3 && rf.w != 0x80000000u) ? __float_as_uint(n3) : 0xffffffffu;
-#else
-        uint32_t k2 = n2 <= f2 ? __float_as_uint(n2) : 0xffffffffu;
-        uint32_t k3 = n3 <= f3 ? __float_as_uint(n3) : 0xffffffffu;
-#endif
-#endif
         uint32_t r0 = rf.x, r1 = rf.y, r2 = rf.z, r3 = rf.w;
 #define PRT_CE(ka, ra, kb, rb)                  \
     {                                           \
@@ -471,15 +360,6 @@ struct Trav {
         if (k1 != 0xffffffffu) {
             stk[sp * 64] = r1;
             sp++;
-#if PRT_PREFETCH_TOP
-            // The entry on top of the stack is what this lane visits after the subtree it descends into now: one dword of
-            // it is requested here (result never used), so that the line is on its way — or in L2 — by the time it is popped.
-            {
-                const int32_t rt = (int32_t)r1;
-                const void* a = rt >= 0 ? static_cast<const void*>(S.nodes + rt) : static_cast<const void*>(tri_at<PAD>(S, (~(uint32_t)rt) >> 3));
-                pf = *static_cast<const volatile uint32_t*>(a);
-            }
-#endif
         }
         if (k0 != 0xffffffffu) {
             cur = (int32_t)r0;
@@ -489,99 +369,8 @@ struct Trav {
             sp--;
             cur = (int32_t)stk[sp * 64];
         }
-#if PRT_DEFER_LEAF
-        // speculative descent (see the 2-wide step): stash the leaf just reached and carry on with the next stack entry
-        if (cur < 0 && cur != PRT_NOCUR && pend == 0) {
-            pend = cur;
-            if (sp == 0) cur = PRT_NOCUR;
-            else {
-                sp--;
-                cur = (int32_t)stk[sp * 64];
-            }
-        }
-#endif
-        if (cur == PRT_NOCUR && pend == 0) active = false;
+        if (cur == PRT_NOCUR) active = false;
     }
-#else
-    // One inner-node visit: fetch the 32-byte node, test both child boxes, descend / push / pop.
-    template <bool COUNT>
-    PRT_DEV void inner_step(const DScene& S, uint32_t* stk, WorkCount& wc) {
-#if PRT_NODE16
-        // 32-byte node = two 16-byte loads: 12 x u16 grid indices (lo,hi pairs) + 2 refs
-        const uint4* np = reinterpret_cast<const uint4*>(S.nodes + cur);
-        const uint4 w0 = np[0], w1 = np[1];
-        float4 a, b, c;
-        a.x = (float)(w0.x & 0xffffu); a.y = (float)(w0.x >> 16);
-        a.z = (float)(w0.y & 0xffffu); a.w = (float)(w0.y >> 16);
-        b.x = (float)(w0.z & 0xffffu); b.y = (float)(w0.z >> 16);
-        b.z = (float)(w0.w & 0xffffu); b.w = (float)(w0.w >> 16);
-        c.x = (float)(w1.x & 0xffffu); c.y = (float)(w1.x >> 16);
-        c.z = (float)(w1.y & 0xffffu); c.w = (float)(w1.y >> 16);
-        int2 refs;
-        refs.x = (int)w1.z;
-        refs.y = (int)w1.w;
-#else
-        const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-        const float4 a = np[0], b = np[1], c = np[2];
-        const int2 refs = *reinterpret_cast<const int2*>(reinterpret_cast<const char*>(S.nodes + cur) + 48);
-#endif
-        if (COUNT) wc.nodes++;
-        // child 0: a = (lo.x,hi.x,lo.y,hi.y), b.xy = (lo.z,hi.z)
-        float l = fmaf(a.x, ax.idq, ax.c_lo), h = fmaf(a.y, ax.idq, ax.c_hi);
-        float n0 = fminf(l, h), f0 = fmaxf(l, h);
-        l = fmaf(a.z, ay.idq, ay.c_lo);
-        h = fmaf(a.w, ay.idq, ay.c_hi);
-        n0 = fmaxf(n0, fminf(l, h));
-        f0 = fminf(f0, fmaxf(l, h));
-        l = fmaf(b.x, az.idq, az.c_lo);
-        h = fmaf(b.y, az.idq, az.c_hi);
-        n0 = fmaxf(fmaxf(n0, fminf(l, h)), tminf);
-        f0 = fminf(fminf(f0, fmaxf(l, h)), tbestf);
-        // child 1: b.zw = (lo.x,hi.x), c = (lo.y,hi.y,lo.z,hi.z)
-        l = fmaf(b.z, ax.idq, ax.c_lo);
-        h = fmaf(b.w, ax.idq, ax.c_hi);
-        float n1 = fminf(l, h), f1 = fmaxf(l, h);
-        l = fmaf(c.x, ay.idq, ay.c_lo);
-        h = fmaf(c.y, ay.idq, ay.c_hi);
-        n1 = fmaxf(n1, fminf(l, h));
-        f1 = fminf(f1, fmaxf(l, h));
-        l = fmaf(c.z, az.idq, az.c_lo);
-        h = fmaf(c.w, az.idq, az.c_hi);
-        n1 = fmaxf(fmaxf(n1, fminf(l, h)), tminf);
-        f1 = fminf(fminf(f1, fmaxf(l, h)), tbestf);
-        const bool h0 = n0 <= f0, h1 = n1 <= f1;
-        if (h0 && h1) {
-            const bool swap = n1 < n0;
-            stk[sp * 64] = (uint32_t)(swap ? refs.x : refs.y);
-            sp++;
-            cur = swap ? refs.y : refs.x;
-        } else if (h0) {
-            cur = refs.x;
-        } else if (h1) {
-            cur = refs.y;
-        } else if (sp == 0) {
-            cur = PRT_NOCUR;
-        } else {
-            sp--;
-            cur = (int32_t)stk[sp * 64];
-        }
-#if PRT_DEFER_LEAF
-        // Speculative descent: a lane that reaches a leaf stashes it (one slot) and carries on with the
-        // next stack entry instead of idling until the wave's next leaf round.  The stashed triangles are
-        // tested later against the then-current closest t; until then this lane culls with a t that
-        // may be stale (a few extra node visits), never with one that is too small.
-        if (cur < 0 && cur != PRT_NOCUR && pend == 0) {
-            pend = cur;
-            if (sp == 0) cur = PRT_NOCUR;
-            else {
-                sp--;
-                cur = (int32_t)stk[sp * 64];
-            }
-        }
-#endif
-        if (cur == PRT_NOCUR && pend == 0) active = false;
-    }
-#endif // PRT_BVH_WIDTH
 
     // fp64 tests of one leaf's triangles (128-byte records); returns true when an early-out hit was accepted.
     template <bool COUNT>
@@ -589,23 +378,17 @@ struct Trav {
         const uint32_t enc = ~(uint32_t)ref;
         const uint32_t first = enc >> 3, cnt = (enc & 7u) + 1u;
         bool stop = false;
-#if PRT_LEAF_PREFETCH
         // The plane part (n, D) of the NEXT triangle is requested before the current one is tested, so its
         // latency overlaps the current test instead of adding to it (the kernels wait on memory half the time).
         // Measured: bathroom2 +4.4 %, veach-mis +2.3 %, S0 +4.5 %, S4 +5.8 %, cornell unchanged; requesting the
         // next triangle's first 64 bytes instead of 32 costs cornell 7 % (registers) and gains nothing elsewhere.
         real4 q0n = *reinterpret_cast<const real4*>(tri_at<PAD>(S, first));
-#endif
         for (uint32_t i = 0; i < cnt; ++i) {
             real t, al, be;
             if (COUNT) wc.tris++;
-#if PRT_LEAF_PREFETCH
             const real4 q0c = q0n;
             if (i + 1 < cnt) q0n = *reinterpret_cast<const real4*>(tri_at<PAD>(S, first + i + 1));
             if (tri_test(tri_at<PAD>(S, first + i), o, d, tmin_use, hit.t, t, al, be, &q0c, COUNT ? &wc.tris_full : nullptr)) {
-#else
-            if (tri_test(tri_at<PAD>(S, first + i), o, d, tmin_use, hit.t, t, al, be, nullptr, COUNT ? &wc.tris_full : nullptr)) {
-#endif
                 hit.t = t;
                 if (!any_hit) { // an any-hit (shadow) traversal only reports THAT something was hit: the barycentrics of the
                     hit.alpha = al; // shading point's own hit stay where they are, for the shading that follows
@@ -619,15 +402,11 @@ struct Trav {
         return stop;
     }
 
-    // Leaf round of this lane: the stashed leaf (reached first, usually nearer), then the current one, then pop.
+    // Leaf round of this lane: the triangles of the leaf it is parked at, then pop.
     template <bool COUNT>
     PRT_DEV void leaf_step(const DScene& S, uint32_t* stk, WorkCount& wc, real tmin_use, bool any_hit) {
         bool stop = false;
-        if (pend != 0) {
-            stop = test_leaf<COUNT>(S, pend, wc, tmin_use, any_hit);
-            pend = 0;
-        }
-        if (!stop && cur < 0 && cur != PRT_NOCUR) {
+        if (cur < 0 && cur != PRT_NOCUR) {
             stop = test_leaf<COUNT>(S, cur, wc, tmin_use, any_hit);
             cur = PRT_NOCUR;
         }
@@ -655,7 +434,7 @@ struct Trav {
         if (COUNT && __ballot(active && cur >= 0) != 0ULL) wc.inner_rounds++;
         if (active && cur >= 0) inner_step<COUNT>(S, stk, wc);
         const bool parked = active && cur < 0;                                   // cannot descend any further right now
-        const bool has_leaf = active && (pend != 0 || (cur < 0 && cur != PRT_NOCUR));
+        const bool has_leaf = active && cur < 0 && cur != PRT_NOCUR;
         const int n_parked = __popcll(__ballot(parked));
         const int n_inner = __popcll(__ballot(active && cur >= 0));
         if (n_parked >= leaf_batch || n_inner <= inner_min) {
@@ -686,10 +465,18 @@ PRT_DEV d3 tex_value(const DScene& S, int ti, real u, real v) {
     real y = (RL(1.) - v) * (tx.height - RL(1.));
     int x0 = (int)x, y0 = (int)y;
     real fx = x - x0, fy = y - y0;
-    const real4* q = reinterpret_cast<const real4*>(S.texels_lin + tx.offset + (size_t)(y0 * tx.width + x0) * PRT_TEX_QUAD_REALS);
-    const real4 q0 = q[0], q1 = q[1], q2 = q[2];
-    d3 c00 = mk3(q0.x, q0.y, q0.z), c10 = mk3(q0.w, q1.x, q1.y);
-    d3 c01 = mk3(q1.z, q1.w, q2.x), c11 = mk3(q2.y, q2.z, q2.w);
+    d3 c00, c10, c01, c11;
+    if (tx.has_data == 1) { // footprint record of cell (x0, y0): the four taps in one 128-byte line
+        const real4* q = reinterpret_cast<const real4*>(S.texels_lin + tx.offset + (size_t)(y0 * tx.width + x0) * PRT_TEX_QUAD_REALS);
+        const real4 q0 = q[0], q1 = q[1], q2 = q[2];
+        c00 = mk3(q0.x, q0.y, q0.z), c10 = mk3(q0.w, q1.x, q1.y);
+        c01 = mk3(q1.z, q1.w, q2.x), c11 = mk3(q2.y, q2.z, q2.w);
+    } else { // plain texel array (textures beyond the scene's footprint budget): Texture.cpp:35-41's four GetPixel calls
+        const int x1 = min(x0 + 1, tx.width - 1), y1 = min(y0 + 1, tx.height - 1);
+        const real* base = S.texels_lin + tx.offset;
+        c00 = ld3(base + ((size_t)y0 * tx.width + x0) * 3), c10 = ld3(base + ((size_t)y0 * tx.width + x1) * 3);
+        c01 = ld3(base + ((size_t)y1 * tx.width + x0) * 3), c11 = ld3(base + ((size_t)y1 * tx.width + x1) * 3);
+    }
     d3 c0 = c00 * (1 - fx) + c10 * fx;
     d3 c1 = c01 * (1 - fx) + c11 * fx;
     return c0 * (1 - fy) + c1 * fy;
@@ -702,11 +489,8 @@ PRT_DEV d3 tex_value(const DScene& S, int ti, real u, real v) {
 // compiler keeps every polynomial coefficient of the kernel in a vector register pair for the whole launch (22 registers
 // of a kernel that sits at its register limit) and evaluates a Horner step as v_mov_b64 tmp, k + v_fmac_f64 tmp, a, b —
 // two vector instructions; scalar moves of the literal issue beside the vector stream.
-#ifndef PRT_FMA_KS
-#define PRT_FMA_KS 1
-#endif
 PRT_DEV double fma_ks(double a, double b, double k) {
-#if PRT_FMA_KS && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
     double r;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
     return r;
@@ -717,7 +501,7 @@ PRT_DEV double fma_ks(double a, double b, double k) {
 PRT_DEV float fma_ks(float a, float b, float k) { return __builtin_fmaf(a, b, k); }
 // a * k + c and a * k with the constant as the multiplier
 PRT_DEV double fma_sk(double a, double k, double c) {
-#if PRT_FMA_KS && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
     double r;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(k), "v"(c));
     return r;
@@ -726,7 +510,7 @@ PRT_DEV double fma_sk(double a, double k, double c) {
 #endif
 }
 PRT_DEV double mul_ks(double a, double k) {
-#if PRT_FMA_KS && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
     double r;
     asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k));
     return r;
@@ -839,13 +623,9 @@ PRT_DEV real sqr(real v) { return v * v; }
 // result is within ~1e-14 relative of pow() — far inside the 1e-9 parity tolerance — at a third of the
 // instructions and registers of the fp64 library pow.  x = 0 -> 0, x < 0 -> NaN (every caller then
 // takes its 'pdf <= 0 / lobe <= 0' branch exactly as with pow's negative/NaN result).
-#ifndef PRT_SLIM_POW
-#define PRT_SLIM_POW 1
-#endif
 PRT_DEV float pow_pos(float x, float y) { // fp32 fast mode: v_exp_f32(y * v_log_f32(x)) (base 2); x = 0 -> exp2(-inf) = 0
     return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
 }
-#if PRT_SLIM_POW
 // Written out (fdlibm's log and a degree-13 exp on the reduced argument, both < 2 ulp) instead of calling the library
 // exp and log: a third of their instructions and, above all, ~25 fewer live registers at the Phong lobe — the
 // difference between 2 and 3 resident waves per SIMD for the Phong permutation.  x is a positive normal number or 0
@@ -888,9 +668,6 @@ PRT_DEV double pow_pos(double x, double y) {
     const double e = __builtin_amdgcn_ldexp(p, (int)n);
     return x > (0.0) ? e : (0.0);
 }
-#else
-PRT_DEV double pow_pos(double x, double y) { return exp(y * log(x)); }
-#endif
 PRT_DEV real fr_complex(real cosTheta_i, Cx eta) { // MaterialUtils.h:100-111
     cosTheta_i = clampd(cosTheta_i, 0, 1);
     real sin2Theta_i = 1 - sqr(cosTheta_i);
@@ -1103,7 +880,8 @@ struct LightPick {
 };
 // `lds_nodes` / `n_lds`: the first n_lds nodes (breadth-first numbering = the top levels of the tree) staged in LDS
 // by the kernel, or null / 0.  The descent is a chain of dependent 16-byte reads, one per tree level (13 for
-// veach-mis's 5120 light triangles); from L1/L2 that chain was 11 % of the veach-mis frame.
+// veach-mis's 6400 light triangles: 11 % of its frame from L1/L2, and the ~30 KB of LDS the top 1800 nodes took cost the
+// Phong permutation its third wave) — since round 4 only the few nodes above the per-mesh TABLES are descended.
 template <bool LLDS>
 PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLightNode* lds_nodes = nullptr, int32_t n_lds = 0,
                                 const DLightTri* lds_tris = nullptr, int32_t n_tris_lds = 0) {
@@ -1112,6 +890,24 @@ PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLig
     float pf = (float)p;
     int32_t node = S.light_root;
     while (node >= 0) {
+        if (node & PRT_LIGHT_TABLE_BIT) {
+            // A subtree on which the descent is a monotone step function of p (prt_types.h, DLightTable): one bucket read gives
+            // the first leaf p can reach and the threshold of the next one; thresholds were found by bisection through this
+            // very descent, so the pick is the descent's bit for bit.
+            const uint4* h = reinterpret_cast<const uint4*>(S.light_tab + 8u * ((uint32_t)node & ~(uint32_t)PRT_LIGHT_TABLE_BIT));
+            const uint4 h0 = h[0];                 // first, n, thr_off, bkt_off
+            const uint2 h1 = *reinterpret_cast<const uint2*>(h + 1); // n_bkt, inv_w
+            const uint32_t k = (uint32_t)fminf(pf * __uint_as_float(h1.y), (float)(h1.x - 1u));
+            const uint2 e = *reinterpret_cast<const uint2*>(S.light_tab + h0.w + 2u * k);
+            uint32_t i = e.x;
+            float next = __uint_as_float(e.y);
+            while (next <= pf) {
+                ++i;
+                next = __uint_as_float(S.light_tab[h0.z + i + 1u]);
+            }
+            node = ~(int32_t)(h0.x + i);
+            break;
+        }
         DLightNode ln;
         if (LLDS && node < n_lds) ln = lds_nodes[node];
         else ln = S.light_nodes[node];

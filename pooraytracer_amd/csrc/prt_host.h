@@ -51,11 +51,18 @@ struct DeviceBVH {
 };
 
 struct LightTree {
-    std::vector<DLightNode> nodes;
-    std::vector<DLightTri> tris; // in area-CDF (leaf) order
-    int32_t root = -1;
+    std::vector<DLightNode> nodes;   // what the kernels descend: the full tree, or (with tables) the part above the tables
+    std::vector<DLightTri> tris;     // in area-CDF (leaf) order
+    int32_t root = -1;               // node index, or a table ref (PRT_LIGHT_TABLE_BIT)
     double area = 0.0;
+    std::vector<uint32_t> tab;       // DLightTable headers + thresholds + buckets (prt_types.h); empty: no tables
+    uint32_t n_tables = 0;
+    std::vector<DLightNode> full_nodes; // the full tree (tests, verification)
+    int32_t full_root = -1;
 };
+// Host twin of the kernels' light pick (prt_device.h, sample_lights): leaf (CDF index) reached by the float p.
+int32_t light_pick(const LightTree& lt, float p);
+int32_t light_pick_full_tree(const LightTree& lt, float p);
 
 // Triangle.cpp:11-53 for every triangle of the description.
 void setup_triangles(const PrtSceneDesc& d, std::vector<HostTri>& out);

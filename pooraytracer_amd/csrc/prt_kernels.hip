@@ -38,10 +38,7 @@
 #else
 #define PRT_NS prt
 #endif
-#ifndef PRT_DYN_STACK64
-#define PRT_DYN_STACK64 0 // measured: a run-time depth costs the fp64 kernels 1.2 % (cornell) and buys them nothing (register-limited)
-#endif
-#define PRT_DYN_STACK (PRT_F32_TU || PRT_DYN_STACK64) // K3's traversal stacks in dynamic LDS, sized per launch from what the scene's tree can need (DRenderParams::stack_depth)
+#define PRT_DYN_STACK PRT_F32_TU // K3's traversal stacks in dynamic LDS, sized per launch from what the scene's tree can need (DRenderParams::stack_depth): the fp32 kernels, which have the registers for a fourth block per CU; the fp64 kernels are register-limited to three and keep static PRT_STACK_DEPTH-entry stacks (a run-time depth cost them 1.2 %)
 
 // minimum resident waves per SIMD the register allocator must leave room for in K3
 #ifndef PRT_RENDER_WAVES
@@ -54,10 +51,7 @@
 #define PRT_RENDER_WAVES_TEX 3  // Lambertian / mirror / light + image textures (bathroom2-class scenes)
 #endif
 #ifndef PRT_RENDER_WAVES_PHONG
-#define PRT_RENDER_WAVES_PHONG 2 // PhoneReflectance without textures (veach-mis-class scenes)
-#endif
-#ifndef PRT_F32_PK_LEAN
-#define PRT_F32_PK_LEAN 1 // lean kernels too since they have the registers (coefficients in scalar registers): fp64 cornell -0.3 %, fp32 no difference
+#define PRT_RENDER_WAVES_PHONG 3 // PhoneReflectance without textures (veach-mis-class scenes): fits since round 3 (168 registers); pays since round 4 (the light tables freed the LDS the third block needs)
 #endif
 #ifndef PRT_F32_WAVES
 #define PRT_F32_WAVES 3 // fp32 fast mode: resident waves per SIMD of every K3 permutation
@@ -69,14 +63,6 @@ constexpr int render_waves(int feat) {
          : feat == PRT_FEAT_PHONG ? PRT_RENDER_WAVES_PHONG
          : PRT_RENDER_WAVES;
 }
-// Paths a wave may keep aside in LDS to trade lanes' finished rays for ones of the kind the pass serves (k_render, "lane pool"):
-// only where LDS is to spare — the fp64 permutations that run two blocks per CU.  MEASURED AND REJECTED (round 3, DESIGN.md §4:
-// parity green, veach-mis 8.7 % and cornell-ct 3 % slower with 24 paths per wave — the exchange costs what the skipped
-// block saves), hence 0; kept as a build option because it is the regrouping experiment the design notes refer to.
-#ifndef PRT_POOL
-#define PRT_POOL 0
-#endif
-constexpr int render_pool(int feat) { return (!PRT_F32_TU && PRT_POOL > 0 && render_waves(feat) == 2) ? PRT_POOL : 0; }
 // The stepping loop of a wave runs while MORE than this many lanes are still traversing; below it the
 // finished lanes are handed new rays (K1) / shaded and re-armed (K3).
 #ifndef PRT_K1_KEEP
@@ -100,18 +86,6 @@ __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
-#ifndef PRT_EARLY_NORMAL
-#define PRT_EARLY_NORMAL 0 // measured: cornell +-0, bathroom2 -0.2 %, veach-mis +1.1 % slower (its plates never use the normal)
-#endif
-#ifndef PRT_ROUND_PRIO
-#define PRT_ROUND_PRIO 0 // s_setprio during traversal rounds: measured cornell -0.9 %, bathroom2 +1.0 %, veach-mis +0.2 %
-#endif
-#ifndef PRT_PASS_PRIO
-#define PRT_PASS_PRIO 0
-#endif
-#ifndef PRT_K3_TIMING
-#define PRT_K3_TIMING 0
-#endif
 #ifndef PRT_K3_PROFILE
 #define PRT_K3_PROFILE 0 // developer diagnostic (COUNT instantiation): shader-clock cycles per section of the wave loop, folded into the counters
 #endif
@@ -120,14 +94,6 @@ __device__ __forceinline__ T wave_sum(T v) {
 #else
 #define PROF_MARK(k) do { } while (0)
 #endif
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
 // ------------------------------------------------------------------------------------------- K1
 // Persistent waves; every lane pulls its next ray from a global counter the moment its traversal
 // ends.  The stepping loop is left (and the finished lanes refilled) once no more than
@@ -208,9 +174,6 @@ __global__ __launch_bounds__(PRT_BLOCK, PRT_K1_WAVES) void k_trace_closest(DScen
             tr.template round<COUNT>(S, stk, wc, PRT_LEAF_BATCH, PRT_INNER_MIN, tr.tmin, false);
         } while (wave_count(tr.active) > PRT_K1_KEEP);
     }
-#if PRT_PREFETCH_TOP
-    asm volatile("" ::"v"(tr.pf));
-#endif
     unsigned long long a = wave_sum((unsigned long long)nrays);
     unsigned long long b = wave_sum((unsigned long long)wc.nodes);
     unsigned long long c = wave_sum((unsigned long long)wc.tris);
@@ -317,14 +280,9 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
     __shared__ uint32_t s_qoff[PRT_BLOCK / 64];
     __shared__ unsigned long long s_rays[PRT_BLOCK / 64];
     __shared__ real s_center[4]; // Camera::center, the origin of every camera ray
-    constexpr int POOL = render_pool(FEAT);              // paths a wave may keep aside (lane pool, below)
-    constexpr int NPARK = PRT_BLOCK + (PRT_BLOCK / 64) * POOL; // one parked camera hit per path in flight: the lanes' and the pool's
-    constexpr int POOL_WORDS = 17 * PRT_RW + 11 + ((FEAT & PRT_FEAT_TEX) ? 2 * PRT_RW : 0); // a path between two traversals, see the exchange below
-    __shared__ uint32_t s_park[PARK_WORDS(FEAT)][NPARK]; // per path: the work item's camera ray and its hit (ST_PRIMARY), read once per sample
-    __shared__ uint32_t s_pool[PRT_BLOCK / 64][POOL ? POOL_WORDS : 1][POOL ? POOL : 1];
-    __shared__ uint16_t s_pidx[PRT_BLOCK / 64][4][POOL ? POOL : 1]; // per wave: slots holding a closest-kind path, a shadow-kind path, free slots, free parking places
-    uint32_t home = threadIdx.x; // where this lane's path parks its camera hit (travels with the path)
-#define park (&s_park[0][home])
+    constexpr int NPARK = PRT_BLOCK;
+    __shared__ uint32_t s_park[PARK_WORDS(FEAT)][NPARK]; // per lane: the work item's camera ray and its hit (ST_PRIMARY), read once per sample
+#define park (&s_park[0][threadIdx.x])
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // Dynamic LDS, sized by the host: the four waves' traversal stacks (P.stack_depth entries per lane, lane-strided),
     // then the shading tables.  The depth is a launch parameter: what the scene's tree can need, not the builders' bound of
@@ -342,10 +300,6 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
     if (lane == 0) {
         s_qoff[wave] = 0;
         s_rays[wave] = 0ULL;
-    }
-    if (POOL > 0 && lane < POOL) { // wave-private: no barrier needed (a wave's LDS operations complete in order)
-        s_pidx[wave][2][lane] = (uint16_t)lane;
-        s_pidx[wave][3][lane] = (uint16_t)(PRT_BLOCK + wave * POOL + lane);
     }
     if (threadIdx.x < 3) s_center[threadIdx.x] = A.C.center[threadIdx.x];
     if (!LLDS) __syncthreads(); // (the LLDS kernels synchronise below, after staging their tables)
@@ -406,12 +360,6 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
     // Rays are counted per WAVE in LDS (ballot + popcount, one 64-bit LDS add by lane 0 per pass: closest | shadow << 32): no
     // register holds a count.  Camera samples are not counted at all: their number follows from the launch (host).
     uint32_t n_refills = 0;
-#if PRT_K3_TIMING
-    // developer diagnostic (COUNT instantiation only): 100 MHz timestamps of this wave's start, of the first
-    // failed item fetch and of its end are folded into inner_rounds / leaf_rounds / refills / tri_tests
-    const unsigned long long tm_start = wall_clock64();
-    unsigned long long tm_dry = 0;
-#endif
 
     int state = ST_FETCH;
     uint32_t item = 0; // work items of a launch are counted in 32 bits (the host refuses more): every division below is a 32-bit one
@@ -430,7 +378,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
     Rng rng;
     rng.s = 0;
     const real inv_spp = RL(1.0) / (real)P.spp; // pixelSamplesScale, Camera.cpp:83
-    Trav<PAD, PRT_BOX_PK && (FEAT != 0 || PRT_F32_PK_LEAN)> tr; // fp32: registers to spare in every permutation
+    Trav<PAD, PRT_BOX_PK != 0> tr; // packed-FMA box test: every K3 permutation has the registers for it (coefficients in scalar registers)
     tr.init(S, mk3(0, 0, 0), rd, RL(0.0), RL(0.0));
     tr.hit.alpha = tr.hit.beta = RL(0.0); // init() leaves the barycentrics alone (they survive shadow traversals)
     tr.active = false;
@@ -438,110 +386,10 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
 #if PRT_K3_PROFILE
     unsigned long long prof_[6] = {0, 0, 0, 0, 0, 0}, prof_t_ = __builtin_readcyclecounter();
 #endif
-    int pool_a = 0, pool_b = 0; // lane pool: paths kept aside whose closest-hit / shadow traversal has finished (wave-uniform)
-    bool dry = false;           // a lane of this wave has found every queue empty: no path is put aside any more
     for (;;) {
         if (COUNT) n_refills++;
         PROF_MARK(0); // traversal rounds (and loop control) since the last mark
         int started = 0; // this pass started a traversal of this kind on this lane (1 closest, 2 shadow): counted below, where the wave has reconverged
-#if PRT_PASS_PRIO
-        __builtin_amdgcn_s_setprio(PRT_PASS_PRIO);
-#endif
-        if (POOL > 0) {
-            // ---------------- lane pool (north_star: "wavefront-level ballot / compaction for active-ray sorting").  A pass
-            // costs the wave every shading block one of its lanes needs, whatever the number of lanes in it; lanes come out of
-            // closest-hit and shadow traversals in about equal numbers, so each block runs a quarter full.  Here the pass
-            // serves ONE kind: the lanes of the other kind trade their paths — everything a path carries between two
-            // traversals, POOL_WORDS dwords — for paths of the served kind that the wave has put aside in LDS earlier (or, while
-            // work items are left, just put theirs aside and fetch a new item).  Paths never leave the wave: no locks, the
-            // bookkeeping is scalar.  The image cannot change (a path's arithmetic does not depend on the lane that runs it).
-            const bool idle = !tr.active;
-            const bool is_a = idle && (state == ST_CLOSEST || state == ST_CACHED), is_b = idle && state == ST_SHADOW, is_d = idle && state == ST_DONE;
-            const unsigned long long m_a = __ballot(is_a), m_b = __ballot(is_b), m_d = __ballot(is_d);
-            const int n_a = __popcll(m_a), n_b = __popcll(m_b), n_d = __popcll(m_d);
-            dry = dry || n_d != 0;
-            const bool serve_a = n_a + pool_a >= n_b + pool_b;          // the kind with more paths at hand
-            const unsigned long long m_m = serve_a ? m_b : m_a;          // lanes of the other kind
-            const int n_m = serve_a ? n_b : n_a, c_s = serve_a ? pool_a : pool_b, c_m = serve_a ? pool_b : pool_a;
-            const int n_free = POOL - pool_a - pool_b;
-            const int k_swap = n_m < c_s ? n_m : c_s;                     // trade
-            const int k_dep = dry ? 0 : ((n_m - k_swap) < n_free ? (n_m - k_swap) : n_free); // put aside, fetch a new item
-            const int k_wd = n_d < (c_s - k_swap) ? n_d : (c_s - k_swap); // lanes out of work take a path back
-            if (k_swap + k_dep + k_wd > 0) {
-                uint16_t* const st_s = s_pidx[wave][serve_a ? 0 : 1];
-                uint16_t* const st_m = s_pidx[wave][serve_a ? 1 : 0];
-                const bool is_m = serve_a ? is_b : is_a;
-                const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_m, 0u));
-                const int r_d = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m_d >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_d, 0u));
-                const bool sw = is_m && r < k_swap, dep = is_m && !sw && r - k_swap < k_dep, wd = is_d && r_d < k_wd;
-                uint32_t slot = 0, new_home = 0;
-                const uint32_t old_home = home;
-                if (sw) slot = st_s[c_s - 1 - r];
-                if (wd) slot = st_s[c_s - k_swap - 1 - r_d];
-                if (dep) {
-                    slot = s_pidx[wave][2][n_free - 1 - (r - k_swap)];
-                    new_home = s_pidx[wave][3][n_free - 1 - (r - k_swap)];
-                }
-                const bool do_load = sw || wd, do_store = sw || dep;
-                if (do_load || do_store) {
-                    uint32_t* const pp = &s_pool[wave][0][slot];
-                    int w = 0;
-                    auto xw = [&](uint32_t& v) { // (a trade reads the slot before it writes it: LDS operations of a lane complete in order)
-                        uint32_t t = v;
-                        if (do_load) t = pp[w * POOL];
-                        if (do_store) pp[w * POOL] = v;
-                        v = t;
-                        ++w;
-                    };
-                    auto xi = [&](int32_t& v) {
-                        uint32_t u = (uint32_t)v;
-                        xw(u);
-                        v = (int32_t)u;
-                    };
-                    auto xr = [&](real& v) {
-                        if (PRT_F32) {
-                            uint32_t u = __float_as_uint((float)v);
-                            xw(u);
-                            v = (real)__uint_as_float(u);
-                        } else {
-                            const unsigned long long b = (unsigned long long)__double_as_longlong((double)v);
-                            uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
-                            xw(lo);
-                            xw(hi);
-                            v = (real)__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-                        }
-                    };
-                    auto x3 = [&](d3& v) { xr(v.x); xr(v.y); xr(v.z); };
-                    uint32_t w0 = (uint32_t)state | (first ? 8u : 0u) | (prev_skip ? 16u : 0u) | ((uint32_t)depth << 5);
-                    xw(w0);
-                    if (do_load) {
-                        state = (int)(w0 & 7u);
-                        first = (w0 & 8u) != 0;
-                        prev_skip = (w0 & 16u) != 0;
-                        depth = (int)(w0 >> 5);
-                    }
-                    xw(item); xi(s); xi(s_end); xw(pixel); xw(home);
-                    uint32_t r0 = (uint32_t)rng.s, r1 = (uint32_t)(rng.s >> 32);
-                    xw(r0); xw(r1);
-                    rng.s = ((uint64_t)r1 << 32) | r0;
-                    x3(pst_[0]); x3(pst_[1]); x3(tr.o); x3(tr.d); xr(tr.hit.t); xi(tr.hit.tri);
-                    if (FEAT & PRT_FEAT_TEX) { xr(tr.hit.alpha); xr(tr.hit.beta); }
-                    x3(rd); xi(sh_tri); xr(ldist); xi(ltri);
-                }
-                if (sw || dep) st_m[c_m + r] = (uint16_t)slot;
-                if (wd) {
-                    s_pidx[wave][2][n_free + r_d] = (uint16_t)slot;
-                    s_pidx[wave][3][n_free + r_d] = (uint16_t)old_home;
-                }
-                if (dep) { // the lane is free for a new work item (fetched further down in this pass)
-                    home = new_home;
-                    state = ST_FETCH;
-                }
-                const int d_s = -(k_swap + k_wd), d_m = k_swap + k_dep;
-                pool_a += serve_a ? d_s : d_m;
-                pool_b += serve_a ? d_m : d_s;
-            }
-        }
         if (!tr.active) {
             // ---------------- a traversal has just finished on this lane: consume its result
             bool end_sample = false, do_scatter = false;
@@ -606,16 +454,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
                     TRACE_VERTEX(-1);
                     end_sample = true;
                 } else {
-#if PRT_EARLY_NORMAL
-                    // The triangle's normal (needed for next-event estimation) is requested TOGETHER with the material index, not
-                    // after the emission test that depends on it: one memory round trip instead of two in a pass whose time
-                    // is mostly such round trips (the pass side is 33-61 % of a frame at 20-25 % of its vector instructions).
-                    d3 gn = ld3(tri_at<PAD>(S, (uint32_t)tr.hit.tri)->n);
-#endif
                     const DMaterial& m = MATERIAL(S.shade[tr.hit.tri].material);
-#if PRT_EARLY_NORMAL
-                    asm volatile("" : "+v"(gn.x), "+v"(gn.y), "+v"(gn.z)); // keeps the request up here (the index above is waited for anyway)
-#endif
                     TRACE_VERTEX(S.shade[tr.hit.tri].prim);
                     if (m.has_emission) {
                         // Camera.cpp:129-132; via a bounce only after SkipLightSampling materials (:191-195)
@@ -628,9 +467,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
                         do_scatter = true;
                         if (P.sample_lights && S.n_lights > 0 && !m.skip_light_sampling) {
                             // next-event estimation, Camera.cpp:137-155: pick the light point now (4 draws)
-#if !PRT_EARLY_NORMAL
                             const d3 gn = ld3(tri_at<PAD>(S, (uint32_t)sh_tri)->n);
-#endif
                             const d3 fn = dot(rd, gn) < RL(0.) ? gn : -gn;
                             const LightPick lp = sample_lights<LLDS>(S, tr.o, rng, lds_lights, P.light_lds, lds_ltris, P.ltri_lds);
                             real dist;
@@ -735,7 +572,6 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
             if (state == ST_FETCH) {
                 const ColdRenderArgs q = cold_args(); // everything a fetch needs is read here, on demand
                 const uint32_t n_items = (uint32_t)q->P.n_items;
-#if PRT_ITEM_QUEUES > 1
                 // One returning atomic per wave and pass on the wave's current queue (the queue index is wave-uniform,
                 // so the compiler aggregates the lanes that execute it); a queue that hands out an index past the end
                 // is dry for good (its indices only grow) and the lanes that drew a blank move on to the next one.
@@ -755,17 +591,8 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
                     }
                     atomicMax(&s_qoff[wave], off);
                 }
-#else
-                {
-                    const unsigned long long it = atomicAdd(&ctr->next_item, 1ULL); // per-lane fetch (the compiler aggregates lanes of one pass)
-                    item = it < n_items ? (uint32_t)it : n_items;
-                }
-#endif
                 if (item >= n_items) {
                     state = ST_DONE;
-#if PRT_K3_TIMING
-                    if (COUNT && tm_dry == 0) tm_dry = wall_clock64();
-#endif
                 } else {
                     const uint32_t ipc = (uint32_t)q->P.items_per_chunk;
                     const uint32_t chunk = item / ipc;
@@ -831,11 +658,6 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
                     tr.o = mk3(s_center[0], s_center[1], s_center[2]);
                     if (PARK_DIR_GLOBAL(FEAT)) { // Camera::GetRay again (same expressions as at the fetch: the same bits)
                         const ColdRenderArgs q = cold_args();
-                        if (POOL > 0) { // px, py do not travel with a path
-                            const int W = q->C.width;
-                            py = (int)(pixel / (uint32_t)W);
-                            px = (int)(pixel - (uint32_t)py * (uint32_t)W);
-                        }
                         const d3 ps = mk3(q->C.pixel00[0], q->C.pixel00[1], q->C.pixel00[2]) + (real)px * mk3(q->C.du[0], q->C.du[1], q->C.du[2]) +
                                       (real)py * mk3(q->C.dv[0], q->C.dv[1], q->C.dv[2]);
                         tr.d = ps - tr.o;
@@ -881,34 +703,22 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
             }
         }
         PROF_MARK(4); // traversal set-up
-#if PRT_PASS_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
         {
             const unsigned long long nc = (unsigned long long)__popcll(__ballot(started == 1)), ns = (unsigned long long)__popcll(__ballot(started == 2));
             if (lane == 0) atomicAdd(&s_rays[wave], nc | (ns << 32));
         }
-        if (__ballot(state != ST_DONE) == 0ULL && pool_a + pool_b == 0) break; // (paths put aside are taken back by the lanes out of work)
+        if (__ballot(state != ST_DONE) == 0ULL) break;
         // Lanes that started a sample from the parked hit have nothing to trace: with enough of them the next pass comes at
         // once (it consumes their hits and hands them real rays) instead of after traversal rounds they would sit out.
         if (wave_count(state == ST_CACHED) >= P.cached_min) continue;
 
         // ---------------- traversal steps until enough lanes have finished to be worth refilling
-#if PRT_ROUND_PRIO
-        __builtin_amdgcn_s_setprio(PRT_ROUND_PRIO); // rounds are short bursts between memory waits: let them cut into other waves' passes
-#endif
         do {
             // the interval's lower end and the any-hit rule follow from the kind of ray: not kept as traversal state
             tr.template round<COUNT>(S, stk, wc, P.leaf_batch, P.inner_min, state == ST_SHADOW ? RL(0.001) : RL(0.0001), state == ST_SHADOW);
         } while (wave_count(tr.active) > P.keep);
-#if PRT_ROUND_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
     }
 
-#if PRT_PREFETCH_TOP
-    asm volatile("" ::"v"(tr.pf));
-#endif
     unsigned long long d = wave_sum((unsigned long long)wc.nodes);
     unsigned long long e = wave_sum((unsigned long long)wc.tris);
     unsigned long long f = wave_sum((unsigned long long)wc.tris_full);
@@ -925,11 +735,6 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
             atomicAdd(&ctr->leaf_rounds, prof_[2]);
             atomicAdd(&ctr->refills, prof_[3]);
             atomicAdd(&ctr->tri_full, prof_[4]);
-#elif PRT_K3_TIMING
-            const unsigned long long tm_end = wall_clock64();
-            atomicMax(&ctr->inner_rounds, ~tm_start);               // -> earliest wave start
-            atomicMax(&ctr->refills, tm_end);                      // -> latest wave end
-            atomicAdd(&ctr->tri_tests, tm_end - tm_start);         // -> sum of wave lifetimes
 #else
             atomicAdd(&ctr->tri_tests, e);
             atomicAdd(&ctr->inner_rounds, (unsigned long long)wc.inner_rounds);
@@ -938,12 +743,6 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
 #endif
         }
     }
-#if PRT_K3_TIMING
-    if (COUNT) {
-        unsigned long long dry = wave_max_u64(tm_dry ? ~tm_dry : 0ULL); // earliest dry fetch within the wave
-        if (lane == 0 && dry) atomicMax(&ctr->leaf_rounds, dry);      // -> earliest dry fetch of the launch
-    }
-#endif
 }
 
 #if !PRT_F32_TU
@@ -1063,10 +862,8 @@ int render_permutation(int feat) {
 int render_lds_budget(int feat, int stack_depth) {
     int blocks = render_waves(render_permutation(feat));
     if (PRT_F32_TU && stack_depth <= 32) blocks = PRT_F32_WAVES > 4 && stack_depth <= 24 ? 5 : 4; // fp32: registers allow a fourth wave per SIMD when the stacks do
-    const int perm = render_permutation(feat), pool = render_pool(perm) * (PRT_BLOCK / 64);
-    const int pool_words = 17 * PRT_RW + 11 + ((perm & PRT_FEAT_TEX) ? 2 * PRT_RW : 0);
-    const int pool_bytes = pool * (int)sizeof(uint32_t) * (pool_words + PARK_WORDS(perm)) + pool * 8; // paths put aside, their parked camera hits, index stacks
-    return ((160 * 1024 / blocks - (int)sizeof(uint32_t) * (stack_depth + PARK_WORDS(perm)) * PRT_BLOCK - pool_bytes - 256) / 512) * 512; // stacks + parked camera rays
+    const int perm = render_permutation(feat);
+    return ((160 * 1024 / blocks - (int)sizeof(uint32_t) * (stack_depth + PARK_WORDS(perm)) * PRT_BLOCK - 256) / 512) * 512; // stacks + parked camera rays
 }
 size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds) {
     return (size_t)light_lds * sizeof(DLightNode) + (size_t)mat_lds * sizeof(DMaterial) + (size_t)ltri_lds * sizeof(DLightTri);

@@ -1,10 +1,9 @@
 // prt_types.h — device-resident data layouts shared by the host builder and the HIP kernels.
 //
 // HBM layout (all arrays are plain hipMalloc allocations, 128-byte aligned):
-//   DNode   [n_nodes]   32 B  BVH2 inner node (PRT_BVH_WIDTH 2): both children's boxes on a 16-bit grid over the scene
-//                             bounds, rounded OUTWARD (conservative cull only; every accept/reject of a hit is
-//                             fp64) + 2 refs; 64 B for the 4-wide node (PRT_BVH_WIDTH 4): four boxes + 4 refs
-//   DTri    [n_tris]   128 B  fp64 intersection record in BVH leaf order (Triangle.cpp:54-83 inputs)
+//   DNode   [n_nodes]   64 B  4-wide BVH node: four children's boxes on a 16-bit grid over the scene bounds, rounded
+//                             OUTWARD (conservative cull only; every accept/reject of a hit is fp64) + 4 refs
+//   DTri    [n_tris]    96 B  fp64 intersection record in BVH leaf order (Triangle.cpp:54-83 inputs; 128-byte stride for HBM-resident scenes)
 //   DTriShade[n_tris]   96 B  fp64 shading record in the same order (tangent, texcoords, material)
 //   DMaterial[n_mat]          material table (Material.h parameters)
 //   DLightNode/DLightTri      the reference's area-CDF light tree (BVH.cpp:86-100), exact fp64 areas
@@ -23,9 +22,7 @@
 #endif
 typedef PRT_REAL prt_real;
 
-#ifndef PRT_BVH_WIDTH
-#define PRT_BVH_WIDTH 4      // children per node: 4 (64-byte nodes, collapsed from the binary tree; measured +11...32 %) or 2 (32-byte nodes)
-#endif
+#define PRT_BVH_WIDTH 4      // children per node (64-byte nodes, collapsed from the binary tree: measured +11...32 % over the binary node)
 #ifndef PRT_STACK_DEPTH
 #define PRT_STACK_DEPTH 40   // LDS traversal stack entries per lane; the builders bound the stack a traversal can need to it.
                              // 40 = 40 KB per 256-thread block: four K1 blocks fill the 160 KB of a CU exactly.  The 4-wide collapse
@@ -39,18 +36,11 @@ typedef PRT_REAL prt_real;
 #define PRT_LEAF_MAX 4       // triangles per BVH leaf (leaf ref stores count-1 in 3 bits)
 #endif
 #define PRT_BLOCK 256        // threads per workgroup (4 wave64)
-#ifndef PRT_LEAF_PREFETCH
-#define PRT_LEAF_PREFETCH 1   // leaf loop requests the next triangle's plane while testing the current one
-#endif
 #define PRT_MAX_CHUNKS 64    // sample chunks per pixel (work items per pixel)
 
-#ifndef PRT_NODE16
-#define PRT_NODE16 1 // 1: 32-byte nodes, boxes quantised to a 16-bit scene grid; 0: 64-byte fp32 nodes
-#endif
-
-#if PRT_BVH_WIDTH == 4
 // 64 bytes = four 16-byte loads per node visit: the x ranges of the four children, their y ranges, their z ranges,
-// the four refs.  A range is lo | hi << 16 on the same 65536^3 grid as the 2-wide node.  Unused slots hold an
+// the four refs.  A range is lo | hi << 16 on a 65536^3 grid over the scene bounds (coordinate = grid_origin + q * grid_step;
+// boxes rounded OUTWARD: a conservative cull only, every accept/reject of a hit is the fp64 triangle test).  Unused slots hold an
 // inverted range (lo = 0xffff, hi = 0) on every axis and ref = 0x80000000; slots fill from the front and every node has
 // at least two children, so only slots 2 and 3 can be unused (the traversal checks their refs).
 struct alignas(64) DNode {
@@ -58,31 +48,7 @@ struct alignas(64) DNode {
     int32_t ref[4]; // >=0: inner node index; <0: leaf, ~ref = (first_tri << 3) | (count-1)
 };
 static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
-#elif PRT_NODE16
-// 32 bytes = two 16-byte loads per node visit (the texture addresser is the limiter, so bytes and
-// load instructions per visit are what count).  Child boxes are quantised OUTWARD onto a 65536^3
-// grid over the scene bounds: coordinate = grid_origin + q * grid_step.
-struct alignas(32) DNode {
-    uint16_t c0x[2], c0y[2], c0z[2]; // child 0: {lo,hi} x,y,z
-    uint16_t c1x[2], c1y[2], c1z[2]; // child 1
-    int32_t ref0, ref1;              // >=0: inner node index; <0: leaf, ~ref = (first_tri << 3) | (count-1)
-};
-static_assert(sizeof(DNode) == 32, "DNode must be 32 bytes");
-#else
-struct alignas(64) DNode {
-    // (lo,hi) pairs per axis so one 16-byte load feeds one axis of one child
-    float c0x[2], c0y[2], c0z[2]; // child 0: {lo,hi} x,y,z
-    float c1x[2], c1y[2], c1z[2]; // child 1
-    int32_t ref0, ref1;           // >=0: inner node index; <0: leaf, ~ref = (first_tri << 3) | (count-1)
-    int32_t pad[2];
-};
-static_assert(sizeof(DNode) == 64, "DNode must be 64 bytes");
-#endif
 
-#ifndef PRT_TRI_FORM
-#define PRT_TRI_FORM 1 // 1: edge functions on a 96-byte record (measured +2...9 %); 0: the reference's expressions on a 128-byte record
-#endif
-#if PRT_TRI_FORM == 1
 // 96 bytes: the plane (n, D) for the interval test, then IsInterior as two edge functions.  With w = n/(n.n):
 //   alpha = w . ((p - v0) x e1) = (p - v0) . (e1 x w) = p . A - a0,   A = e1 x w, a0 = v0 . A
 //   beta  = w . (e0 x (p - v0)) = (p - v0) . (w x e0) = p . B - b0,   B = w x e0, b0 = v0 . B
@@ -100,33 +66,17 @@ struct alignas(4 * sizeof(R)) DTriT {
 };
 typedef DTriT<prt_real> DTri;
 static_assert(sizeof(DTriT<double>) == 96 && sizeof(DTriT<float>) == 48, "DTri must be 96 / 48 bytes");
-#else
-template <typename R>
-struct alignas(16 * sizeof(R)) DTriT {
-    R n[3];   // unit geometric normal        (Triangle.cpp:19)
-    R D;      // dot(normal, v0)              (Triangle.cpp:50)
-    R w[3];   // n / dot(n,n), n = e0 x e1    (Triangle.cpp:51)
-    R v0[3];
-    R e0[3];  // v1 - v0
-    R e1[3];  // v2 - v0
-};
-typedef DTriT<prt_real> DTri;
-static_assert(sizeof(DTriT<double>) == 128, "DTri must be 128 bytes");
-#endif
 
-#ifndef PRT_SHADE_PADDED
-#define PRT_SHADE_PADDED 0 // 1: shading records one per 128-byte line instead of packed at 96 / 48 bytes — measured: cornell +2.3 %, bathroom2 +1.2 % slower
-#endif
 template <typename R>
-struct alignas(PRT_SHADE_PADDED ? 16 * sizeof(R) : 4 * sizeof(R)) DTriShadeT {
+struct alignas(4 * sizeof(R)) DTriShadeT {
     R tangent[3]; // Triangle.cpp:31-46
     R uv0[2], uv1[2], uv2[2];
     int32_t material;
     int32_t prim;      // index in PrtSceneDesc order
-    R pad[PRT_SHADE_PADDED ? (sizeof(R) == 8 ? 6 : 5) : (sizeof(R) == 8 ? 2 : 1)];
+    R pad[sizeof(R) == 8 ? 2 : 1];
 };
 typedef DTriShadeT<prt_real> DTriShade;
-static_assert(sizeof(DTriShadeT<double>) == (PRT_SHADE_PADDED ? 128 : 96) && sizeof(DTriShadeT<float>) == (PRT_SHADE_PADDED ? 64 : 48), "DTriShade must be 96 / 48 (128 / 64) bytes");
+static_assert(sizeof(DTriShadeT<double>) == 96 && sizeof(DTriShadeT<float>) == 48, "DTriShade must be 96 / 48 bytes");
 
 template <typename R>
 struct alignas(16) DMaterialT {
@@ -143,8 +93,10 @@ struct alignas(16) DMaterialT {
 typedef DMaterialT<prt_real> DMaterial;
 static_assert(sizeof(DMaterialT<double>) == 192 && sizeof(DMaterialT<float>) % 16 == 0, "materials are staged into LDS in 16-byte pieces");
 
+#define PRT_TEX_FOOTPRINT_BUDGET (256ull << 20) // fp64 bytes of footprint records a scene may hold; textures beyond it stay plain texel arrays
 struct DTexture {
-    int32_t width, height, channels, has_data;
+    int32_t width, height, channels;
+    int32_t has_data; // 0: no texels (Value() = (0,1,1)); 1: bilinear footprints, 16 reals per texel cell; 2: row-major texels, 3 reals each
     uint64_t offset; // index of the texture's first real in texels_lin
 };
 
@@ -155,6 +107,29 @@ struct alignas(16) DLightNodeT {
 };
 typedef DLightNodeT<prt_real> DLightNode;
 static_assert(sizeof(DLightNodeT<double>) == 16 && sizeof(DLightNodeT<float>) == 16, "light nodes are 16 bytes");
+
+// O(1) light pick (round 4).  TraverseSample (BVH.cpp:86-100) is a monotone step function of its float `p` on every
+// subtree that holds no span-1 node over a node (left == right: BVH.cpp:21-23 — there `p >= area` wraps around to the first
+// triangle): float subtraction and comparison are monotone, so the leaf reached can only move right as p grows.  For such a
+// subtree the host finds, by bisection over float bit patterns THROUGH THE DESCENT ITSELF, the smallest p that reaches each
+// leaf (thr[i]), and the kernel replaces the descent of the subtree — 11 dependent reads per pick for a 1280-triangle
+// mesh — by one bucket read (value-linear buckets, ~2 per leaf: entry = first candidate leaf + the next threshold) and,
+// now and then, a short walk along thr[].  The picks are the descent's bit for bit (verified on the host at every
+// threshold +- 1 ulp, every bucket edge and 2^16 random p; a scene that fails keeps the tree).  The part of the tree
+// above the tables (span-1 nodes, the few nodes over the meshes) is still descended with the reference's arithmetic.
+// A node ref with PRT_LIGHT_TABLE_BIT set names a table: ref & ~BIT = index of its DLightTable in DScene::light_tab.
+#define PRT_LIGHT_TABLE_BIT 0x40000000
+#define PRT_LIGHT_TABLE_MIN 16 // leaves a subtree needs to get a table
+struct DLightTable {   // 32 bytes, at uint32 offset 8 * index of light_tab
+    uint32_t first;    // CDF index of the subtree's first leaf
+    uint32_t n;        // its leaves
+    uint32_t thr_off;  // uint32 offset in light_tab of thr[0..n] (floats; thr[0] = 0, thr[n] = +inf)
+    uint32_t bkt_off;  // uint32 offset of the bucket entries {uint32 first candidate, float next threshold}
+    uint32_t n_bkt;
+    float inv_w;       // bucket(p) = min(n_bkt - 1, (uint32)(p * inv_w))
+    uint32_t pad_[2];
+};
+static_assert(sizeof(DLightTable) == 32, "DLightTable is 32 bytes");
 
 template <typename R>
 struct alignas(sizeof(R) == 8 ? 128 : 16) DLightTriT {
@@ -178,14 +153,15 @@ struct DSceneT {
     const R* texels_lin; // linearised texels (GetPixel() of Texture.cpp:50-65 evaluated on the host) as bilinear footprints: 16 reals per cell (prt_device.h, tex_value)
     const DLightNodeT<R>* light_nodes;
     const DLightTriT<R>* light_tris;
+    const uint32_t* light_tab; // DLightTable headers, then their thresholds and buckets (null: no tables)
     int32_t light_root; // ref into light tree; valid iff n_lights > 0
     int32_t n_lights;
     R light_area;  // GetArea() of the top-level lights BVHNode
     uint32_t n_nodes, n_tris;
-    float slab_scale;   // E of the slab test's pad (prt_device.h, slab_axis): PRT_NODE16 the largest extent of the quantisation
-                        // grid (box coordinates are taken relative to its origin); fp32 nodes: the largest |coordinate| of any box
+    float slab_scale;   // E of the slab test's pad (prt_device.h, slab_axis): the largest extent of the quantisation
+                        // grid (box coordinates are taken relative to its origin)
     float pad_;
-    float grid_origin[3]; // PRT_NODE16: box coordinate = grid_origin + q * grid_step
+    float grid_origin[3]; // box coordinate = grid_origin + q * grid_step
     float grid_step[3];
     uint32_t tri_stride;  // bytes between consecutive DTri records: sizeof(DTri), or the padded stride for HBM-resident scenes
     uint32_t pad2_;
@@ -226,9 +202,7 @@ typedef DRenderParamsT<prt_real> DRenderParams;
 // atomics per microsecond, which the short items at the end of a launch (and every launch at low spp) exceed.
 // Queue q owns the 64-item blocks b with b % PRT_ITEM_QUEUES == q, in ascending order; a workgroup starts at queue
 // blockIdx % PRT_ITEM_QUEUES and moves on to the next one when its queue runs dry.
-#ifndef PRT_ITEM_QUEUES
 #define PRT_ITEM_QUEUES 16
-#endif
 #define PRT_QUEUE_STRIDE 32 // in 8-byte words: one counter per 256 bytes (different memory channels)
 #define PRT_ITEMS_FROM_LIST 2 // DRenderParams::scramble: pixels come from DCounters::pixel_list (prt_render_samples)
 

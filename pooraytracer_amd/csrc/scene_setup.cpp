@@ -249,6 +249,228 @@ int32_t flatten_light(const RefBuilder& rb, const Obj& o, LightTree& out, const 
 
 } // namespace
 
+// ---------------------------------------------------------------------------------------------
+// O(1) light pick: threshold + bucket tables for the subtrees on which TraverseSample is monotone (prt_types.h, DLightTable).
+namespace {
+inline float bits_float(uint32_t b) {
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+inline uint32_t float_bits(float f) {
+    uint32_t b;
+    std::memcpy(&b, &f, 4);
+    return b;
+}
+// BVHNode::TraverseSample (BVH.cpp:86-100) on the flattened nodes, as sample_lights executes it: the comparison and the
+// subtraction in double, p truncated to float at every level (the parameter's type, BVH.h:32).  Returns the leaf's CDF index.
+int32_t descend(const std::vector<DLightNode>& nodes, int32_t node, float p) {
+    while (node >= 0) {
+        const DLightNode& ln = nodes[node];
+        if ((double)p < ln.left_area) node = ln.left;
+        else {
+            p = (float)((double)p - ln.left_area);
+            node = ln.right;
+        }
+    }
+    return ~node;
+}
+inline uint32_t bucket_of(float p, float inv_w, uint32_t n_bkt) { // the kernel's expression, operation for operation
+    const float x = std::fmin(p * inv_w, (float)(n_bkt - 1));
+    return (uint32_t)x;
+}
+// smallest float bit pattern b in [0, 0x7f7fffff] (positive floats order like their patterns) with pred(bits_float(b)); 0x7f800000 if none
+template <typename Pred>
+uint32_t first_pattern(Pred pred) {
+    if (!pred(bits_float(0x7f7fffffu))) return 0x7f800000u;
+    uint32_t lo = 0, hi = 0x7f7fffffu; // invariant: pred(hi)
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (pred(bits_float(mid))) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+int32_t table_pick(const uint32_t* tab, uint32_t table, float p) { // host twin of the kernel's table lookup
+    DLightTable t;
+    std::memcpy(&t, tab + 8 * (size_t)table, sizeof(t));
+    const uint32_t k = bucket_of(p, t.inv_w, t.n_bkt);
+    uint32_t i = tab[t.bkt_off + 2 * k];
+    float next = bits_float(tab[t.bkt_off + 2 * k + 1]);
+    while (next <= p) {
+        ++i;
+        next = bits_float(tab[t.thr_off + i + 1]);
+    }
+    return (int32_t)(t.first + i);
+}
+} // namespace
+
+int32_t light_pick_full_tree(const LightTree& lt, float p) { return descend(lt.full_nodes, lt.full_root, p); }
+int32_t light_pick(const LightTree& lt, float p) {
+    int32_t node = lt.root;
+    while (node >= 0) {
+        if (node & PRT_LIGHT_TABLE_BIT) return table_pick(lt.tab.data(), (uint32_t)node & ~(uint32_t)PRT_LIGHT_TABLE_BIT, p);
+        const DLightNode& ln = lt.nodes[node];
+        if ((double)p < ln.left_area) node = ln.left;
+        else {
+            p = (float)((double)p - ln.left_area);
+            node = ln.right;
+        }
+    }
+    return ~node;
+}
+
+static void build_light_tables(LightTree& out) {
+    const std::vector<DLightNode>& full = out.full_nodes;
+    const size_t nn = full.size();
+    if (out.full_root < 0 || nn == 0) return;
+    // per node: leaves of the subtree (contiguous in CDF order: the flattening is depth-first, left to right), its area as
+    // the reference sums it, and whether TraverseSample is monotone on it (no span-1 node over a node inside)
+    std::vector<uint32_t> first(nn, 0), count(nn, 0);
+    std::vector<uint8_t> clean(nn, 1);
+    std::vector<double> area(nn, 0.0);
+    // children come after their parent in the breadth-first numbering: one backward sweep is a post-order
+    auto leaf_first = [&](int32_t ref) { return ref < 0 ? (uint32_t)~ref : first[ref]; };
+    auto leaf_count = [&](int32_t ref) { return ref < 0 ? 1u : count[ref]; };
+    auto ref_area = [&](int32_t ref) { return ref < 0 ? out.tris[~ref].area : area[ref]; };
+    for (size_t k = nn; k-- > 0;) {
+        const DLightNode& n = full[k];
+        const bool single = n.left == n.right;
+        first[k] = leaf_first(n.left);
+        count[k] = single ? leaf_count(n.left) : leaf_count(n.left) + leaf_count(n.right);
+        area[k] = single ? ref_area(n.left) : ref_area(n.left) + ref_area(n.right); // BVH.cpp:21-45
+        clean[k] = !(single && n.left >= 0) && (n.left < 0 || clean[n.left]) && (n.right < 0 || clean[n.right]);
+    }
+    std::vector<uint32_t> hdr, body; // headers first (8 words each), then thresholds / buckets; offsets fixed up at the end
+    struct Made { int32_t node; uint32_t table; };
+    std::vector<Made> made;
+    std::vector<int32_t> stack{out.full_root};
+    while (!stack.empty()) {
+        const int32_t k = stack.back();
+        stack.pop_back();
+        if (clean[k] && count[k] >= PRT_LIGHT_TABLE_MIN) {
+            const uint32_t n = count[k], f0 = first[k];
+            DLightTable t{};
+            t.first = f0;
+            t.n = n;
+            t.thr_off = (uint32_t)body.size();
+            // thr[i]: the smallest p whose descent reaches leaf f0 + i or one to its right
+            body.push_back(float_bits(0.f));
+            for (uint32_t i = 1; i < n; ++i)
+                body.push_back(first_pattern([&](float p) { return descend(full, k, p) >= (int32_t)(f0 + i); }));
+            body.push_back(0x7f800000u); // thr[n] = +inf ends every walk
+            uint32_t nb = 1;
+            while (nb < 2 * n && nb < (1u << 20)) nb <<= 1;
+            t.n_bkt = nb;
+            t.inv_w = (float)((double)nb / area[k]);
+            if (!(t.inv_w > 0.f) || !std::isfinite(t.inv_w)) { // degenerate areas: no table for this subtree
+                body.resize(t.thr_off);
+                if (full[k].left >= 0) stack.push_back(full[k].left);
+                if (full[k].right >= 0 && full[k].right != full[k].left) stack.push_back(full[k].right);
+                continue;
+            }
+            t.bkt_off = (uint32_t)body.size();
+            const uint32_t* thr = nullptr;
+            for (uint32_t b = 0; b < nb; ++b) {
+                const uint32_t pat = first_pattern([&](float p) { return bucket_of(p, t.inv_w, nb) >= b; });
+                uint32_t i = n - 1; // a bucket no p falls into: anything valid
+                if (pat != 0x7f800000u) i = (uint32_t)descend(full, k, bits_float(pat)) - f0;
+                thr = body.data() + t.thr_off;
+                const uint32_t next = thr[i + 1];
+                body.push_back(i);
+                body.push_back(next);
+            }
+            made.push_back({k, (uint32_t)(hdr.size() / 8)});
+            uint32_t w[8];
+            std::memcpy(w, &t, sizeof(t));
+            hdr.insert(hdr.end(), w, w + 8);
+            continue;
+        }
+        if (full[k].left >= 0) stack.push_back(full[k].left);
+        if (full[k].right >= 0 && full[k].right != full[k].left) stack.push_back(full[k].right);
+    }
+    if (made.empty()) return;
+    const uint32_t shift = (uint32_t)hdr.size();
+    for (size_t t = 0; t < made.size(); ++t) {
+        hdr[8 * t + 2] += shift; // thr_off
+        hdr[8 * t + 3] += shift; // bkt_off
+    }
+    std::vector<uint32_t> tab(hdr);
+    tab.insert(tab.end(), body.begin(), body.end());
+    // the part of the tree above the tables, renumbered breadth-first (K3 stages it in LDS: a handful of nodes)
+    std::vector<int32_t> table_of(nn, -1);
+    for (const Made& m : made) table_of[m.node] = (int32_t)m.table;
+    auto map_ref = [&](int32_t ref, const std::vector<int32_t>& newidx) {
+        if (ref < 0) return ref;
+        if (table_of[ref] >= 0) return (int32_t)(PRT_LIGHT_TABLE_BIT | (uint32_t)table_of[ref]);
+        return newidx[ref];
+    };
+    std::vector<int32_t> order, newidx(nn, -1);
+    if (table_of[out.full_root] < 0) order.push_back(out.full_root);
+    for (size_t q = 0; q < order.size(); ++q) {
+        const DLightNode& n = full[order[q]];
+        if (n.left >= 0 && table_of[n.left] < 0) order.push_back(n.left);
+        if (n.right >= 0 && n.right != n.left && table_of[n.right] < 0) order.push_back(n.right);
+    }
+    for (size_t i = 0; i < order.size(); ++i) newidx[order[i]] = (int32_t)i;
+    std::vector<DLightNode> top(order.size());
+    for (size_t i = 0; i < order.size(); ++i) {
+        DLightNode n = full[order[i]];
+        n.left = map_ref(n.left, newidx);
+        n.right = map_ref(n.right, newidx);
+        top[i] = n;
+    }
+    LightTree cand = out;
+    cand.nodes = top;
+    cand.root = map_ref(out.full_root, newidx);
+    cand.tab = tab;
+    cand.n_tables = (uint32_t)made.size();
+    // Verification: the table pick must be the descent's at every threshold and one pattern below it, at both ends of every
+    // bucket, at 0, at the areas, far beyond them, and at 2^16 random patterns per table — through the WHOLE tree (the top
+    // part included), against the full tree.  Any difference and the scene keeps the tree.
+    auto same = [&](float p) { return light_pick(cand, p) == descend(full, out.full_root, p); };
+    bool ok = true;
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    const float total = (float)out.area;
+    for (const Made& m : made) {
+        DLightTable t;
+        std::memcpy(&t, tab.data() + 8 * (size_t)m.table, sizeof(t));
+        // p as the table sees it is what is left of the root's p after the top part's subtractions: test the table's own
+        // domain through table_pick / descend on the subtree, and the whole pick through the root
+        auto same_sub = [&](float p) { return table_pick(tab.data(), m.table, p) == descend(full, m.node, p); };
+        for (uint32_t i = 0; i <= t.n && ok; ++i) {
+            const uint32_t b = tab[t.thr_off + i];
+            if (b != 0x7f800000u) ok = ok && same_sub(bits_float(b));
+            if (b != 0 && b <= 0x7f800000u) ok = ok && same_sub(bits_float(b - 1));
+            if (b < 0x7f7fffffu) ok = ok && same_sub(bits_float(b + 1));
+        }
+        for (uint32_t b = 0; b < t.n_bkt && ok; ++b) {
+            const uint32_t pat = first_pattern([&](float p) { return bucket_of(p, t.inv_w, t.n_bkt) >= b; });
+            if (pat == 0x7f800000u) continue;
+            ok = ok && same_sub(bits_float(pat));
+            if (pat) ok = ok && same_sub(bits_float(pat - 1));
+        }
+        const uint32_t top_pat = float_bits((float)(2.0 * area[m.node]));
+        for (int r = 0; r < 65536 && ok; ++r) {
+            rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+            ok = ok && same_sub(bits_float((uint32_t)(rng % ((uint64_t)top_pat + 1))));
+        }
+        ok = ok && same_sub(0.f) && same_sub((float)area[m.node]) && same_sub(3.0e38f) && same_sub(1e-30f);
+    }
+    const uint32_t tot_pat = float_bits(total);
+    for (int r = 0; r < 262144 && ok; ++r) { // the whole pick, over the patterns p = (float)(sqrt(xi) * area) can take
+        rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+        ok = ok && same(bits_float((uint32_t)(rng % ((uint64_t)tot_pat + 1))));
+    }
+    for (uint32_t b = tot_pat > 64 ? tot_pat - 64 : 0; b <= tot_pat + 64 && ok; ++b) ok = ok && same(bits_float(b)); // the wrap-around region
+    ok = ok && same(0.f);
+    if (!ok) return;
+    out.nodes.swap(cand.nodes);
+    out.root = cand.root;
+    out.tab.swap(cand.tab);
+    out.n_tables = cand.n_tables;
+}
+
 void build_light_tree(const PrtSceneDesc& d, const std::vector<HostTri>& tris, const std::vector<DMaterial>& mats,
                       LightTree& out) {
     out.nodes.clear();
@@ -294,6 +516,11 @@ void build_light_tree(const PrtSceneDesc& d, const std::vector<HostTri>& tris, c
         out.nodes.swap(renum);
         out.root = 0;
     }
+    out.full_nodes = out.nodes;
+    out.full_root = out.root;
+    out.tab.clear();
+    out.n_tables = 0;
+    build_light_tables(out);
     for (DLightTri& lt : out.tris) { // Triangle::Sample pdf = 1/area; TraverseSample pdf *= area; BVHNode::Sample pdf /= total
         double pdf = 1.0 / lt.area;
         pdf *= lt.area;

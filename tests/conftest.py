@@ -26,3 +26,12 @@ def gpu(prt_lib):
     if api.device_count() < 1:
         pytest.fail("no HIP device visible: -m gpu tests need a real GPU (there is no CPU fallback)")
     return 0
+
+
+@pytest.fixture
+def dev_lib(gpu):
+    """Scenes created inside this test come from libprt_hip_dev.so: the -DPRT_DEV_HOOKS=1 build of the same sources, the
+    only one that reads the PRT_TUNE_* / PRT_TEST_* environment hooks (failure injection, forced layouts)."""
+    from pooraytracer_amd import api
+    with api.dev_hooks() as L:
+        yield L

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <string>
 #include <vector>
@@ -53,7 +54,6 @@ static int check_tree(const BuiltBVH& b, const std::vector<HostTri>& tris) {
         }
         if ((size_t)it.ref >= b.nodes.size()) return fail("node index");
         const DNode& nd = b.nodes[it.ref];
-#if PRT_BVH_WIDTH == 4
         int kids = 0;
         for (int i = 0; i < 4; ++i) {
             if (nd.ref[i] == (int32_t)0x80000000) {
@@ -75,17 +75,9 @@ static int check_tree(const BuiltBVH& b, const std::vector<HostTri>& tris) {
         }
         if (kids < 2) return fail("wide node with fewer than two children");
         continue;
-#else
-        Box c0, c1;
-        deq(nd.c0x, 0, c0.lo[0], c0.hi[0]); deq(nd.c0y, 1, c0.lo[1], c0.hi[1]); deq(nd.c0z, 2, c0.lo[2], c0.hi[2]);
-        deq(nd.c1x, 0, c1.lo[0], c1.hi[0]); deq(nd.c1y, 1, c1.lo[1], c1.hi[1]); deq(nd.c1z, 2, c1.lo[2], c1.hi[2]);
-        stack.push_back({nd.ref0, c0, it.depth + 1});
-        if (!(n == 1 && nd.ref1 == nd.ref0)) stack.push_back({nd.ref1, c1, it.depth + 1});
-#endif
     }
     for (size_t i = 0; i < n; ++i)
         if (seen[i] != 1) return fail("triangle not in exactly one leaf");
-#if PRT_BVH_WIDTH == 4
     // worst-case stack use of a traversal: entering a node with k children leaves up to k-1 siblings on the stack
     std::vector<int> need(b.nodes.size(), 0);
     for (size_t i = b.nodes.size(); i-- > 0;) { // children have larger indices than their parent
@@ -101,9 +93,7 @@ static int check_tree(const BuiltBVH& b, const std::vector<HostTri>& tris) {
         need[i] = k - 1 + worst;
     }
     if (!need.empty() && need[0] > PRT_STACK_DEPTH) return fail("a traversal could overflow the stack");
-#else
-    if (max_depth > PRT_STACK_DEPTH - 1) return fail("tree deeper than the traversal stack");
-#endif
+    (void)max_depth;
     return 0;
 }
 
@@ -134,6 +124,12 @@ int main() {
         mats[0].type = PRT_MAT_LAMBERTIAN; mats[0].texture = -1; mats[0].kd[0] = mats[0].kd[1] = mats[0].kd[2] = 0.5;
         mats[1].type = PRT_MAT_DIFFUSE_LIGHT; mats[1].texture = -1; mats[1].emission[0] = 5;
         const size_t n_light = n >= 37 ? n / 10 : 0;
+        // lights: one emissive mesh (a span-1 top node: the wrap-around case), or — last round — three of unequal size (the
+        // lights BVH over them then holds a span-1 node INSIDE: BVH.cpp:21-23 with span 3 -> 1 + 2)
+        const bool three = round == 4;
+        const size_t l0 = n - n_light, l1 = l0 + n_light / 2, l2 = l1 + n_light / 3;
+        const uint64_t first3[5] = {0, l0, l1, l2, n};
+        const int32_t mm3[4] = {0, 1, 1, 1};
         const uint64_t first[3] = {0, n - n_light, n};
         const int32_t mm[2] = {0, 1};
         PrtSceneDesc d = {};
@@ -141,6 +137,11 @@ int main() {
         d.n_meshes = n_light ? 2 : 1; d.n_materials = 2; d.mesh_first_tri = first; d.mesh_material = mm; d.materials = mats;
         const uint64_t first1[2] = {0, n};
         if (!n_light) d.mesh_first_tri = first1;
+        if (three) {
+            d.n_meshes = 4;
+            d.mesh_first_tri = first3;
+            d.mesh_material = mm3;
+        }
         std::vector<HostTri> tris;
         setup_triangles(d, tris);
         std::vector<DMaterial> dm;
@@ -148,18 +149,57 @@ int main() {
         LightTree lt;
         build_light_tree(d, tris, dm, lt);
         if (lt.tris.size() != n_light) return fail("light triangle count");
-        if (n_light && (lt.root != 0 && lt.nodes.size() > 0)) return fail("light tree root is not node 0 after renumbering");
+        const bool root_is_table = lt.root >= 0 && (lt.root & PRT_LIGHT_TABLE_BIT);
+        if (n_light && !root_is_table && lt.root != 0 && lt.nodes.size() > 0) return fail("light tree root is not node 0 after renumbering");
+        auto bad_ref = [&](int32_t r) {
+            if (r < 0) return (size_t)(~r) >= lt.tris.size();
+            if (r & PRT_LIGHT_TABLE_BIT) return (uint32_t)(r & ~PRT_LIGHT_TABLE_BIT) >= lt.n_tables;
+            return (size_t)r >= lt.nodes.size();
+        };
         for (const DLightNode& ln : lt.nodes)
-            if ((ln.left >= 0 && (size_t)ln.left >= lt.nodes.size()) || (ln.right >= 0 && (size_t)ln.right >= lt.nodes.size()) ||
-                (ln.left < 0 && (size_t)(~ln.left) >= lt.tris.size()) || (ln.right < 0 && (size_t)(~ln.right) >= lt.tris.size()))
-                return fail("light tree reference out of range");
+            if (bad_ref(ln.left) || bad_ref(ln.right)) return fail("light tree reference out of range");
+        if (n_light >= PRT_LIGHT_TABLE_MIN) {
+            // O(1) light pick: tables exist (one per emissive mesh), the nodes the kernels still descend are the few above them,
+            // and the pick equals the full tree's descent — at every threshold and its neighbours, over a window of EVERY float
+            // around the total area (p = sqrt(xi) * area rounds up to it: the wrap-around of a span-1 node), and on 2e6 random p
+            if (lt.n_tables != (three ? 2u : 1u)) return fail("light tables: one per maximal span-1-free subtree expected (one mesh: 1; three: the lone mesh and the pair)");
+            if (lt.nodes.size() > 8) return fail("light tables: the top part should be a handful of nodes");
+            auto fbits = [](float f) { uint32_t b; std::memcpy(&b, &f, 4); return b; };
+            auto bfloat = [](uint32_t b) { float f; std::memcpy(&f, &b, 4); return f; };
+            size_t checked = 0;
+            auto same = [&](float p) { ++checked; return light_pick(lt, p) == light_pick_full_tree(lt, p); };
+            for (uint32_t t = 0; t < lt.n_tables; ++t) {
+                DLightTable h;
+                std::memcpy(&h, lt.tab.data() + 8 * (size_t)t, sizeof(h));
+                for (uint32_t i = 0; i <= h.n; ++i) {
+                    const uint32_t b = lt.tab[h.thr_off + i];
+                    for (int dlt = -2; dlt <= 2; ++dlt) {
+                        const uint32_t q = b + (uint32_t)dlt;
+                        if (q <= 0x7f7fffffu && !same(bfloat(q))) return fail("light pick differs from the descent next to a threshold");
+                    }
+                }
+            }
+            const uint32_t tot = fbits((float)lt.area);
+            for (uint32_t b = tot - 5000; b <= tot + 5000; ++b)
+                if (!same(bfloat(b))) return fail("light pick differs from the descent near the total area (wrap-around)");
+            std::uniform_int_distribution<uint32_t> P(0, tot + 1000);
+            for (int k = 0; k < 2000000; ++k)
+                if (!same(bfloat(P(rng)))) return fail("light pick differs from the descent at a random p");
+            // the descent's leaf moves right with p on every table's subtree: sampled monotonicity of the full pick below the wrap
+            int32_t last = -1;
+            for (uint32_t b = 0; b < tot; b += 257) {
+                const int32_t leaf = light_pick_full_tree(lt, bfloat(b));
+                if (!three && leaf < last) return fail("descent not monotone on a one-mesh lights list below the total area");
+                last = leaf;
+            }
+            std::printf("light tables: %u tables, %zu top nodes, %zu words, %zu picks compared\n", lt.n_tables, lt.nodes.size(), lt.tab.size(), checked);
+        }
         BuiltBVH b;
         std::string err;
         if (!build_bvh(tris, b, &err)) return fail(err.c_str());
         if (b.order.size() != n) return fail("order size");
         if (check_tree(b, tris)) return 1;
         if (!validate_nodes(b.nodes.data(), b.nodes.size(), n, &err)) return fail(err.c_str());
-#if PRT_BVH_WIDTH == 4
         // the second collapse (small LDS stacks, fp32 render kernels): present exactly when the first one can need more
         // than PRT_STACK_SHALLOW entries, a well-formed tree over the same leaves, and within that bound itself
         if (b.stack_need != tree_stack_need(b.nodes.data(), b.nodes.size())) return fail("stack_need is not the tree's");
@@ -172,7 +212,6 @@ int main() {
             if (tree_stack_need(sh.nodes.data(), sh.nodes.size()) > PRT_STACK_SHALLOW) return fail("shallow tree needs more than its budget");
             ++n_shallow;
         }
-#endif
         std::vector<double> moved(v);
         for (double& x : moved) x = x * 1.5 + 0.25;
         update_triangles(moved.data(), nullptr, tris);

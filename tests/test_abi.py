@@ -167,13 +167,12 @@ def test_cmake_build_produces_the_same_libraries(tmp_path):
     assert "libpooraytracer_host.so" in ldd and "libprt_hip.so" in ldd
 
 
-@pytest.mark.parametrize("flags", [["-DPRT_BVH_WIDTH=2"], ["-DPRT_TRI_FORM=0", "-DPRT_FAST_F64=0"], ["-DPRT_ITEM_QUEUES=1", "-DPRT_K3_PROFILE=1"], ["-DPRT_POOL=24"],
-                                   ["-DPRT_FMA_KS=0", "-DPRT_PREFETCH_TOP=1", "-DPRT_F32_PK_LEAN=0"]])
+@pytest.mark.parametrize("flags", [["-DPRT_K3_PROFILE=1"], ["-DPRT_DEV_HOOKS=1"]])
 def test_alternative_build_configurations_still_compile(flags):
-    """The A/B switches DESIGN.md quotes measurements for (2-wide nodes, the reference's triangle expressions on 128-byte
-    records, IEEE sqrt / division in the shading code, one work-item counter, the per-section profile) are compile-time
-    options of the same sources: they must keep compiling (semantic analysis incl. every kernel instantiation, host
-    and gfx950 passes; no code generation, so this takes seconds)."""
+    """Two build options of the product sources remain: the per-section cycle stamps of K3's wave loop (instrumentation for
+    tools/exp_profile.py) and the developer / test environment hooks (libprt_hip_dev.so; exercised for RESULTS by the -m gpu
+    tests that take the `dev_lib` fixture).  The rejected A/B experiments of rounds 1-3 live in experiments/, not behind
+    switches.  Semantic analysis incl. every kernel instantiation, host and gfx950 passes; no code generation."""
     import shutil
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle
-from pooraytracer_amd import api, build, distributed, scenes
+from pooraytracer_amd import _abi, api, build, distributed, scenes
 
 pytestmark = pytest.mark.gpu
 
@@ -76,14 +76,10 @@ def test_render_multi_on_one_device_and_over_rccl(gpu):
         api.render_multi([reps[0], reps[0]], spp=2, max_depth=2)
     with pytest.raises(api.PrtError):
         api.render_multi([reps[0], api.Scene(data)], spp=2, max_depth=2)
-    # a communicator of ONE rank: everything of the RCCL branch a one-GPU box can run (ncclCommInitAll, grouped ncclReduce on
-    # the device framebuffer, stream order, the copy back)
-    os.environ["PRT_TEST_FORCE_RCCL"] = "1"
-    try:
-        for _ in range(2):
-            assert np.array_equal(api.render_multi(reps[:1], spp=6, max_depth=6, seed=3), want)
-    finally:
-        del os.environ["PRT_TEST_FORCE_RCCL"]
+    # the caller's current device is restored, and prt_shutdown may be called any number of times
+    api.shutdown()
+    api.shutdown()
+    assert np.array_equal(api.render_multi(reps, spp=6, max_depth=6, seed=3), want)
     ndev = api.device_count()
     if ndev >= 2:
         n = min(ndev, 4)
@@ -93,6 +89,53 @@ def test_render_multi_on_one_device_and_over_rccl(gpu):
         if n >= 3:
             with pytest.raises(api.PrtError):  # two on device 0, one on device 1: neither all-distinct nor all-same
                 api.render_multi([spread[0], reps[0], spread[1]], spp=2, max_depth=2)
+
+
+def test_render_multi_rccl_branch_with_one_rank_and_injected_failures(gpu, dev_lib, monkeypatch):
+    """The RCCL branch of prt_render_multi as far as ONE GPU allows, in the dev-hooks build of the library:
+    PRT_TEST_FORCE_RCCL sends a single scene through it — ncclCommInitAll with one rank, the grouped ncclReduce on the device
+    framebuffer, stream order, the copy back; PRT_TEST_FAIL_NCCL=init|reduce makes that step report a failure: the call must
+    fail with PRT_E_HIP (group closed, failed communicators dropped), leave the scene usable, and the next frames — through
+    RCCL again (communicators re-created) and on the plain single-device path — are bit-identical to prt_render's."""
+    data = scenes.mixed_materials(72, 56)
+    sc = api.Scene(data).upload(gpu)
+    assert sc._L.prt_dev_hooks() == 1
+    _, want = sc.render(spp=6, max_depth=6, seed=3, f32=True)
+    kw = dict(spp=6, max_depth=6, seed=3)
+    monkeypatch.setenv("PRT_TEST_FORCE_RCCL", "1")
+    for _ in range(2):  # the second frame reuses the cached communicator
+        assert np.array_equal(api.render_multi([sc], **kw), want)
+    for step in ("reduce", "init"):
+        if step == "init":
+            sc._L.prt_shutdown()  # no cached communicator: the next call has to create one
+        monkeypatch.setenv("PRT_TEST_FAIL_NCCL", step)
+        with pytest.raises(api.PrtError) as e:
+            api.render_multi([sc], **kw)
+        assert e.value.code == _abi.PRT_E_HIP and ("ncclReduce failed" if step == "reduce" else "ncclCommInitAll failed") in str(e.value)
+        monkeypatch.delenv("PRT_TEST_FAIL_NCCL")
+        assert np.array_equal(api.render_multi([sc], **kw), want)          # RCCL branch again, fresh communicator
+        assert np.array_equal(sc.render(f32=True, **kw)[1], want)          # and the scene's own render
+    monkeypatch.delenv("PRT_TEST_FORCE_RCCL")
+    assert np.array_equal(api.render_multi([sc], **kw), want)              # n == 1 without the hook: no collective
+    sc._L.prt_shutdown()
+    sc.close()
+
+
+def test_shipped_library_reads_no_environment_hooks(gpu, monkeypatch):
+    """the PRT_TUNE_* / PRT_TEST_* hooks are compiled into libprt_hip_dev.so only.  With the variables set,
+    the shipped library uploads (no injected failure), keeps its LDS tables and its packed records, and renders the same
+    frame as without them."""
+    data = scenes.tiny_scene()
+    ref = api.Scene(data).upload(gpu)
+    assert ref._L.prt_dev_hooks() == 0
+    want = ref.render(spp=3, max_depth=5, seed=2)
+    for k, v in (("PRT_TEST_FAIL_UPLOAD", "0"), ("PRT_TUNE_TRI_STRIDE", "128"), ("PRT_TUNE_NO_LDS", "1"), ("PRT_TUNE_KEEP", "63"),
+                 ("PRT_TUNE_CACHED_MIN", "0"), ("PRT_TUNE_SCRAMBLE", "2"), ("PRT_TEST_FAIL_NCCL", "init"), ("PRT_TEST_FORCE_RCCL", "1")):
+        monkeypatch.setenv(k, v)
+    sc = api.Scene(data).upload(gpu)
+    assert sc.bvh_info()["tri_stride"] == 96
+    assert np.array_equal(sc.render(spp=3, max_depth=5, seed=2), want)
+    assert np.array_equal(api.render_multi([sc], spp=3, max_depth=5, seed=2), want.astype(np.float32))
 
 
 def test_camera_xml_override(gpu, tmp_path):
@@ -262,6 +305,9 @@ def test_bench_parity_check_fails_the_run_when_pixels_differ(gpu, monkeypatch):
     assert r.returncode != 0 and lines and lines[-1]["parity_check"]["ok"] is False and lines[-1]["checks_ok"] is False
     r, lines = _bench(["--steps", "1", "--warmup", "0", "--spp", "4", "--no-extra"], {})
     pc = lines[-1]["parity_check"]
-    assert lines[-1]["cpu_baseline"]["cores"] == len(os.sched_getaffinity(0)) and lines[-1]["config"]["ray_definition"]
+    cb = lines[-1]["cpu_baseline"]
+    # the CPU baseline runs on the fastest worker count of a scan up to the whole affinity mask, and says which
+    assert str(cb["cores"]) in {str(k) for k in cb["thread_scan_mpaths_per_s"]} and cb["affinity_cores"] == len(os.sched_getaffinity(0))
+    assert lines[-1]["config"]["ray_definition"]
     # a knife-edge branch may flip in a handful of the ~10^6 pixels (tolerance: 0.1 % of them); everything else is within 1e-9
     assert r.returncode == 0 and pc["ok"] is True and pc["bad_px"] <= 1e-4 * pc["pixels"]

@@ -436,7 +436,7 @@ def test_device_bvh_build_gives_identical_results(gpu, name, scene_fn, nrays):
 
 
 @pytest.mark.gpu
-def test_lds_tables_and_plain_kernels_agree(gpu, monkeypatch):
+def test_lds_tables_and_plain_kernels_agree(gpu, dev_lib, monkeypatch):
     """K3 has two kernel families: with the material table / light triangles / top of the light tree staged in LDS
     (default when the materials fit in 8 KB) and without.  Same arithmetic, so the images must be bit-identical —
     on a few-light scene (light triangles staged), a many-light scene (only the top of the tree staged, the rest
@@ -546,7 +546,7 @@ def test_far_ray_origins_end_and_hit_what_the_oracle_hits(gpu, dist):
     assert abs(img.mean() - ref.mean()) <= 0.05 * ref.mean()  # camera rays tie between neighbouring triangles at this distance
 
 
-def test_failed_upload_leaves_scene_unusable_but_sane(gpu, monkeypatch):
+def test_failed_upload_leaves_scene_unusable_but_sane(gpu, dev_lib, monkeypatch):
     """a failure in the middle of prt_scene_upload must not leave a half-filled device scene behind
     (prt_sample_lights would launch on null tables).  PRT_TEST_FAIL_UPLOAD=k makes the k-th table upload report
     out-of-memory; afterwards every compute call must refuse cleanly and a later upload must work."""
@@ -708,7 +708,7 @@ def test_counters_report_the_tree_that_is_resident(gpu):
         assert 0 < c["tri_full"] <= c["tri_tests"]
 
 
-def test_padded_and_packed_triangle_records_agree(gpu, monkeypatch):
+def test_padded_and_packed_triangle_records_agree(gpu, dev_lib, monkeypatch):
     """Intersection records are packed (96 bytes apart) for scenes the caches hold and padded to one per 128-byte line
     for scenes that stream from HBM (> 256 MB of records); each layout has its own kernel instantiations.  Forcing
     the padded layout on a small scene must give bit-identical hits and frames, for both builders."""
@@ -962,3 +962,69 @@ def test_whole_frame_equals_the_oracle_on_every_pixel(gpu, name, factory, depth)
     cnt = sc.counters()
     assert cnt["samples"] == ocnt["samples"] == cam.width * cam.height * 8
     sc.close()
+
+
+def test_texture_footprints_have_a_ceiling(gpu):
+    """VERDICT r3 #6 (ImageTexture::Value, Source/Texture.cpp:22-71): textures are stored as bilinear footprints (128 bytes per
+    texel, one line per lookup) only while a scene's footprints stay within 256 MiB, smallest texture first; what does not
+    fit stays a plain texel array (24 bytes per texel).  A 4096^2 map next to a 512^2 one: the small one gets footprints, the
+    large one does not, the scene uploads in < 0.5 GB of texels instead of 2.2 GB, and the frame equals the oracle's."""
+    import copy
+    data = copy.copy(scenes.bathroom(96, 54, detail=0.15))
+    big = np.tile(data.textures[0], (8, 8, 1))                   # 4096 x 4096 x 3
+    assert big.shape == (4096, 4096, 3)
+    data.textures = [big, data.textures[1]]
+    sc = api.Scene(data).upload(gpu)
+    info = sc.bvh_info()
+    assert info["texture_layouts"] == 3                                           # both layouts in use
+    assert info["texture_footprint_bytes"] == 512 * 512 * 128                     # the small texture
+    assert info["texture_bytes"] == 512 * 512 * 128 + 4096 * 4096 * 24 < 0.5e9    # (as footprints: 2.2 GB)
+    img = sc.render(spp=4, max_depth=6, seed=5)
+    ref, _ = oracle.Oracle(data).render(spp=4, max_depth=6, seed=5, nthreads=8)
+    compare_images(img, ref)
+    # the fp32 fast mode derives its tables from the same array (either layout)
+    img32 = sc.render(spp=4, max_depth=6, seed=5, precision=1)
+    assert np.isfinite(img32).all() and abs(img32.mean() - ref.mean()) <= 2e-3 * ref.mean()
+    sc.close()
+    # the stand-in scenes are far below the ceiling: footprints only, as measured in DESIGN.md
+    small = api.Scene(scenes.bathroom(96, 54, detail=0.15)).upload(gpu)
+    assert small.bvh_info()["texture_layouts"] == 1 and small.bvh_info()["texture_bytes"] == 2 * 512 * 512 * 128
+
+
+def test_texture_layouts_give_the_same_frame(gpu, dev_lib, monkeypatch):
+    """Same doubles, same blend: with the footprint budget forced to 0 (dev-hooks library) every texture stays a plain texel
+    array and the frame is the footprint build's bit for bit."""
+    data = scenes.bathroom(96, 54, detail=0.15)
+    a = api.Scene(data).upload(gpu)
+    assert a.bvh_info()["texture_layouts"] == 1
+    monkeypatch.setenv("PRT_TUNE_TEX_BUDGET", "0")
+    b = api.Scene(data).upload(gpu)
+    assert b.bvh_info()["texture_layouts"] == 2 and b.bvh_info()["texture_footprint_bytes"] == 0
+    kw = dict(spp=4, max_depth=6, seed=5)
+    assert np.array_equal(a.render(**kw), b.render(**kw))
+    uv = np.random.default_rng(3).uniform(-0.2, 1.2, size=(4096, 2))
+    assert np.array_equal(a.texture_value(0, uv), b.texture_value(0, uv))
+
+
+def test_many_materials_on_a_deep_tree_keep_their_occupancy(gpu):
+    """ADVICE r3 (prt_api.cpp, LDS budget): the fp64 render kernels keep static 40-entry stacks, so their table budget is what
+    THOSE leave at the permutation's occupancy — a deep host-built tree with ~35 materials used to be moved to the 32-entry
+    tree and given tables sized for stacks the kernel does not have, which cost a resident block.  Now: the full tree, and
+    tables only when the occupancy query says they cost nothing."""
+    import copy
+    base = scenes.bathroom(96, 54, detail=1.0)        # 126k triangles: the deep tree of BASELINE config 4
+    for extra in (0, 25, 60):
+        data = copy.copy(base)
+        data.materials = list(base.materials) + [base.materials[3]] * extra
+        sc = api.Scene(data).upload(gpu)
+        info = sc.bvh_info()
+        assert info["stack_need"] > 32                                            # a tree the 32-entry collapse would change
+        assert info["render_blocks_per_cu"] == info["render_blocks_wanted"] == 3, info   # textured permutation: three blocks per CU
+        if extra == 0:
+            assert info["lds_materials"] == len(data.materials)                   # ten materials fit beside the stacks
+            ref_img = sc.render(spp=2, max_depth=6, seed=9)
+        else:
+            # more materials than the ~5 KB beside three blocks' stacks hold: no tables, still three blocks; same frame
+            assert info["lds_materials"] in (0, len(data.materials))
+            assert np.array_equal(sc.render(spp=2, max_depth=6, seed=9), ref_img)
+        sc.close()

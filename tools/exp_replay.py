@@ -2,6 +2,7 @@
 ray stream (every traversal it starts, in the order its waves start them: PRT_TUNE_DUMP_RAYS) is replayed through K1 — pure
 traversal, every lane refilled the moment it finishes, nothing else in the wave's way — and the frame's traversal time at
 that rate is set against the frame's K3 time.  Also replayed shuffled (incoherent) and sorted by origin (coherent)."""
+import os as _os; _os.environ.setdefault("PRT_DEV_LIB", "1")  # the PRT_TUNE_* hooks exist in libprt_hip_dev.so only
 import json, os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np

@@ -1,4 +1,5 @@
 """Developer tool: wave-level round statistics of K3 (counting instantiation)."""
+import os as _os; _os.environ.setdefault("PRT_DEV_LIB", "1")  # the PRT_TUNE_* hooks exist in libprt_hip_dev.so only
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch

@@ -1,4 +1,5 @@
 """Developer tool: K3 time of one rank's 1/N tile share under different item schedules (PRT_TUNE_* overrides)."""
+import os as _os; _os.environ.setdefault("PRT_DEV_LIB", "1")  # the PRT_TUNE_* hooks exist in libprt_hip_dev.so only
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch

@@ -1,6 +1,7 @@
 """Whole-frame parity at the BASELINE configurations: every pixel of the fp64 GPU frame against the oracle's frame of the
 same (spp, depth, seed) — not only the rows bench.py samples.  Writes gpurun_out/r03_full_frame_parity.json.
 The oracle runs on the box's 16 host threads (about a minute per frame)."""
+import os as _os; _os.environ.setdefault("PRT_DEV_LIB", "1")  # the PRT_TUNE_* hooks exist in libprt_hip_dev.so only
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

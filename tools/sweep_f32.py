@@ -1,4 +1,5 @@
 """Developer tool: K3 scheduling thresholds (keep / leaf_batch / inner_min) swept for the fp32 kernels (PRT_PREC=1) or the fp64 ones."""
+import os as _os; _os.environ.setdefault("PRT_DEV_LIB", "1")  # the PRT_TUNE_* hooks exist in libprt_hip_dev.so only
 import os, sys, itertools
 sys.path.insert(0, os.getcwd())
 import torch

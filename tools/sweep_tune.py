@@ -1,5 +1,6 @@
 """Developer tool: sweep the wave-scheduling thresholds of K3 (PRT_TUNE_KEEP / LEAF_BATCH / INNER_MIN are read by
 prt_render_device at every call) for one library build, on the three render scenes at reduced spp."""
+import os as _os; _os.environ.setdefault("PRT_DEV_LIB", "1")  # the PRT_TUNE_* hooks exist in libprt_hip_dev.so only
 import itertools, os, sys
 sys.path.insert(0, os.getcwd())
 import torch
