@@ -1026,5 +1026,6 @@ def test_many_materials_on_a_deep_tree_keep_their_occupancy(gpu):
         else:
             # more materials than the ~5 KB beside three blocks' stacks hold: no tables, still three blocks; same frame
             assert info["lds_materials"] in (0, len(data.materials))
-            assert np.array_equal(sc.render(spp=2, max_depth=6, seed=9), ref_img)
+            # (the kernels with and without LDS tables are separate compilations: FMA contraction may differ, the tolerance applies)
+            compare_images(sc.render(spp=2, max_depth=6, seed=9), ref_img)
         sc.close()
