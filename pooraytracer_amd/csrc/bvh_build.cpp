@@ -359,6 +359,21 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
         b.build(0, (uint32_t)n, kMaxLevels, 0, root, true);
     }
     out.depth = b.max_depth;
+    out.binary.clear();
+    if (out.keep_binary) { // tools/sim_oct8.cpp
+        out.binary.resize(fn.size());
+        for (size_t i = 0; i < fn.size(); ++i) {
+            BuiltBVH::BinNode& o = out.binary[i];
+            const float* src[2][3] = {{fn[i].c0x, fn[i].c0y, fn[i].c0z}, {fn[i].c1x, fn[i].c1y, fn[i].c1z}};
+            for (int c = 0; c < 2; ++c)
+                for (int a = 0; a < 3; ++a) {
+                    o.lo[c][a] = src[c][a][0];
+                    o.hi[c][a] = src[c][a][1];
+                }
+            o.ref[0] = fn[i].ref0;
+            o.ref[1] = fn[i].ref1;
+        }
+    }
     float cs = 0.f;
     for (const PrimRef& pr : b.prims)
         for (int a = 0; a < 3; ++a) cs = std::max(cs, std::max(std::fabs(pr.lo[a]), std::fabs(pr.hi[a])));

@@ -29,7 +29,14 @@ struct BuiltBVH {
     std::vector<uint32_t> order; // BVH leaf order -> index into the HostTri array
     uint32_t depth = 0;
     float coord_scale = 1.0f;    // >= |every box coordinate|
-    float grid_origin[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1}; // PRT_NODE16 quantisation grid
+    float grid_origin[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1}; // quantisation grid of the 16-bit boxes
+    // tools/sim_oct8.cpp only: the binary SAH tree the wide nodes were collapsed from (pre-order; refs as in DNode)
+    struct BinNode {
+        float lo[2][3], hi[2][3];
+        int32_t ref[2];
+    };
+    bool keep_binary = false;
+    std::vector<BinNode> binary;
 };
 
 // fp32 box of one triangle for the BVH builders: HostTri::lo/hi rounded outward + a small absolute inflation
@@ -37,7 +44,7 @@ struct PrimBox {
     float lo[3], hi[3];
 };
 void prim_boxes(const std::vector<HostTri>& tris, std::vector<PrimBox>& out);
-// PRT_NODE16 quantisation grid over the root box (origin rounds down, 65535 steps reach past hi).
+// quantisation grid of the 16-bit boxes over the root box (origin rounds down, 65535 steps reach past hi).
 void quant_grid(const float root_lo[3], const float root_hi[3], bool empty, float origin[3], float step[3]);
 
 // BVH built on the device (bvh_build_gpu.hip): nodes and the triangle permutation stay in HBM.
