@@ -53,16 +53,16 @@ PEAK_CLOCK_GHZ = 2.4
 # at 1-4 waves per SIMD (profiles/r03_valu_calibration.json: plain fp32 / integer ALU ops issue every ~2.2-2.6 cycles per
 # SIMD, everything else K1 / K3 use — fp64, conversions, v_alignbit, min / max, v_cndmask, compares, v_pk_fma_f32 — every
 # ~4.2, reciprocals 8-16), tools/price_mix.py prices each permutation's ISA with that, weighted by the wave-level counters
-# of the counting build (profiles/r03_valu_mix.json).  Fallback when that file has no entry: 4.2 cycles per instruction.
+# of the counting build (profiles/r04_valu_mix.json).  Fallback when that file has no entry: 4.2 cycles per instruction.
 VALU_FALLBACK_GINST = N_SIMD * PEAK_CLOCK_GHZ / 4.2
 
 
 def valu_peak(workload):
     try:
-        mix = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_mix.json")))["workloads"]
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r04_valu_mix.json")))["workloads"]
         e = mix.get(workload) or mix.get(workload.split("-spp")[0] + ("-f32" if workload.endswith("-f32") else ""))
         if e:
-            return float(e["issue_ceiling_ginstr_per_s"]), float(e["avg_cycles_per_valu_instruction"]), "profiles/r03_valu_mix.json"
+            return float(e["issue_ceiling_ginstr_per_s"]), float(e["avg_cycles_per_valu_instruction"]), "profiles/r04_valu_mix.json"
     except Exception:
         pass
     return VALU_FALLBACK_GINST, 4.2, "fallback: 4.2 cycles per vector instruction (profiles/r03_valu_calibration.json, fp64 / conversion class)"

@@ -69,10 +69,14 @@ def load():
     L.prt_texture_value.argtypes = [vp, i32, sz, vp, vp]
     L.prt_render_samples.argtypes = [vp, vp, vp, vp, sz, i32, i32, vp, vp]
     L.prt_render_multi.argtypes = [vp, i32, vp, vp, vp]
-    if L.prt_abi_version() != _abi.PRT_ABI_VERSION:
+    if L.prt_abi_version() != _abi.PRT_ABI_VERSION and os.environ.get("PRT_ABI_ANY") != "1":  # (PRT_ABI_ANY: A/B tools timing an older build)
         raise PrtError(-101, "ABI version mismatch between _abi.py and libprt_hip.so")
-    L.prt_shutdown.restype = None
-    L.prt_dev_hooks.restype = C.c_int
+    try:
+        L.prt_shutdown.restype = None
+        L.prt_dev_hooks.restype = C.c_int
+    except AttributeError:
+        if os.environ.get("PRT_ABI_ANY") != "1":
+            raise
     _libs[_LIB_PATH] = L
     return L
 

@@ -889,25 +889,9 @@ PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLig
     real p = ieee_sqrt(rng.next()) * S.light_area; // IEEE: p is truncated to float and compared against the CDF — the pick stays bit-exact
     float pf = (float)p;
     int32_t node = S.light_root;
-    while (node >= 0) {
-        if (node & PRT_LIGHT_TABLE_BIT) {
-            // A subtree on which the descent is a monotone step function of p (prt_types.h, DLightTable): one bucket read gives
-            // the first leaf p can reach and the threshold of the next one; thresholds were found by bisection through this
-            // very descent, so the pick is the descent's bit for bit.
-            const uint4* h = reinterpret_cast<const uint4*>(S.light_tab + 8u * ((uint32_t)node & ~(uint32_t)PRT_LIGHT_TABLE_BIT));
-            const uint4 h0 = h[0];                 // first, n, thr_off, bkt_off
-            const uint2 h1 = *reinterpret_cast<const uint2*>(h + 1); // n_bkt, inv_w
-            const uint32_t k = (uint32_t)fminf(pf * __uint_as_float(h1.y), (float)(h1.x - 1u));
-            const uint2 e = *reinterpret_cast<const uint2*>(S.light_tab + h0.w + 2u * k);
-            uint32_t i = e.x;
-            float next = __uint_as_float(e.y);
-            while (next <= pf) {
-                ++i;
-                next = __uint_as_float(S.light_tab[h0.z + i + 1u]);
-            }
-            node = ~(int32_t)(h0.x + i);
-            break;
-        }
+    // plain node refs are below PRT_LIGHT_TABLE_BIT, table refs at or above it, leaf refs negative: ONE unsigned compare per
+    // level, as before the tables existed (a scene without tables pays one more compare per pick, after the loop)
+    while ((uint32_t)node < (uint32_t)PRT_LIGHT_TABLE_BIT) {
         DLightNode ln;
         if (LLDS && node < n_lds) ln = lds_nodes[node];
         else ln = S.light_nodes[node];
@@ -916,6 +900,23 @@ PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLig
             pf = (float)((real)pf - ln.left_area);
             node = ln.right;
         }
+    }
+    if (node >= 0) {
+        // A subtree on which the descent is a monotone step function of p (prt_types.h, DLightTable): one bucket read gives
+        // the first leaf p can reach and the threshold of the next one; thresholds were found by bisection through this
+        // very descent, so the pick is the descent's bit for bit.
+        const uint4* h = reinterpret_cast<const uint4*>(S.light_tab + 8u * ((uint32_t)node & ~(uint32_t)PRT_LIGHT_TABLE_BIT));
+        const uint4 h0 = h[0];                                   // first, n, thr_off, bkt_off
+        const uint2 h1 = *reinterpret_cast<const uint2*>(h + 1); // n_bkt, inv_w
+        const uint32_t k = (uint32_t)fminf(pf * __uint_as_float(h1.y), (float)(h1.x - 1u));
+        const uint2 e = *reinterpret_cast<const uint2*>(S.light_tab + h0.w + 2u * k);
+        uint32_t i = e.x;
+        float next = __uint_as_float(e.y);
+        while (next <= pf) {
+            ++i;
+            next = __uint_as_float(S.light_tab[h0.z + i + 1u]);
+        }
+        node = ~(int32_t)(h0.x + i);
     }
     LightPick lp;
     lp.tri = ~node;

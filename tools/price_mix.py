@@ -4,10 +4,10 @@
 For every render permutation: the kernel's ISA (hipcc -S, no GPU needed) is cut into basic blocks, the blocks are sorted
 into node round / leaf round / triangle loop / shade pass by the loops they sit in, every block's vector instructions are
 priced per class (cycles per wave64 instruction per SIMD at the kernel's occupancy), and the blocks are weighted with the
-wave-level counters of the counting build on that workload (profiles/r03_wave_stats.json: node rounds, leaf rounds,
+wave-level counters of the counting build on that workload (profiles/r04_wave_stats.json: node rounds, leaf rounds,
 passes per 64 rays).  Result: the average issue cost of one vector instruction of THAT kernel on THAT workload, hence the
 issue ceiling in wave-instructions per second — the denominator of bench.py's `valu` roofline — written to
-profiles/r03_valu_mix.json.  The predicted dynamic instruction count per ray is printed next to the counters' own
+profiles/r04_valu_mix.json.  The predicted dynamic instruction count per ray is printed next to the counters' own
 (SQ_INSTS_VALU / rays, profiles/pmc_summary.json) as a check of the weighting.
 """
 import json
@@ -53,7 +53,7 @@ CLASS = [
 ]
 
 # permutation -> (FEAT template argument, workload that runs it, resident waves per SIMD of the fp64 / fp32 kernel)
-PERMS = {"cornell-box": (0, 3, 4), "bathroom2": (1, 3, 4), "veach-mis": (2, 2, 4), "cornell-ct": (4, 2, 4)}
+PERMS = {"cornell-box": (0, 3, 4), "bathroom2": (1, 3, 4), "veach-mis": (2, 3, 4), "cornell-ct": (4, 2, 4)}
 
 
 def asm_of(f32):
@@ -109,13 +109,13 @@ def classify(op, cal, w, unknown):
 
 def main():
     cal = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_calibration.json")))["ops"]
-    stats = json.load(open(os.path.join(ROOT, "profiles", "r03_wave_stats.json")))
+    stats = json.load(open(os.path.join(ROOT, "profiles", "r04_wave_stats.json")))
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json")))
     except Exception:
         pmc = {}
     clock = 2.4
-    result = {"source": "tools/price_mix.py: ISA of k_render x profiles/r03_valu_calibration.json x profiles/r03_wave_stats.json",
+    result = {"source": "tools/price_mix.py: ISA of k_render x profiles/r03_valu_calibration.json x profiles/r04_wave_stats.json",
               "clock_ghz": clock, "simds": N_SIMD, "workloads": {}}
     for f32 in (False, True):
         src = asm_of(f32)
@@ -166,7 +166,7 @@ def main():
             # counters when they exist for this build (SQ_INSTS_VALU per ray minus the traversal's share) at the pass's own mix
             pm = pmc.get(name) or {}
             cpl = pm.get("counters_per_launch", {})
-            fresh = str(pm.get("round", "")).startswith("r03")
+            fresh = str(pm.get("round", "")).startswith("r04")
             pmc_per_ray = cpl["SQ_INSTS_VALU"] / pm["rays_per_launch"] if fresh and "SQ_INSTS_VALU" in cpl and pm.get("rays_per_launch") else None
             pmc_cost = 4.0 * cpl["SQ_ACTIVE_INST_VALU"] / cpl["SQ_INSTS_VALU"] if pmc_per_ray and "SQ_ACTIVE_INST_VALU" in cpl else None
             trav = sum(tot[k][0] * weights[k] for k in ("node", "leaf", "tri"))
@@ -192,7 +192,7 @@ def main():
             print(f"{name:16s} feat {feat} w{w}: static VALU node {tot['node'][0]} leaf {tot['leaf'][0]} tri {tot['tri'][0]} pass {tot['pass'][0]} | "
                   f"predicted {per_ray:.1f} VALU/ray (PMC {entry['pmc_valu_per_ray']}) | avg {avg:.2f} cycles/instr -> ceiling {entry['issue_ceiling_ginstr_per_s']} G/s"
                   + (f" | unclassified {unknown}" if unknown else ""))
-    json.dump(result, open(os.path.join(ROOT, "profiles", "r03_valu_mix.json"), "w"), indent=1)
+    json.dump(result, open(os.path.join(ROOT, "profiles", "r04_valu_mix.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

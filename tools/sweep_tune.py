@@ -10,7 +10,10 @@ keeps = [int(x) for x in os.environ.get("SW_KEEP", "16,20,24,28,32").split(",")]
 lbs = [int(x) for x in os.environ.get("SW_LB", "32").split(",")]
 ims = [int(x) for x in os.environ.get("SW_IM", "12").split(",")]
 cms = [int(x) for x in os.environ.get("SW_CM", "65").split(",")]
+which = os.environ.get("SW_SCENES", "cornell,bathroom,veach").split(",")
 for name, fn, spp, depth in (("cornell", scenes.cornell_box, 125, 20), ("bathroom", scenes.bathroom, 50, 50), ("veach", scenes.veach_mis, 200, 100)):
+    if name not in which:
+        continue
     data = fn(); sc = api.Scene(data).upload(0); cam = data.camera
     fb = torch.zeros((cam.height, cam.width, 3), dtype=torch.float32, device="cuda")
     sc.render_device(None, fb.data_ptr(), spp=4, max_depth=depth); torch.cuda.synchronize()

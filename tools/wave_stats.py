@@ -1,5 +1,5 @@
 """Developer tool: wave-level statistics of K3's counting instantiation per workload (node rounds, leaf rounds, passes per
-64 rays; VALU-relevant weights for tools/price_mix.py).  Writes gpurun_out/r03_wave_stats.json."""
+64 rays; VALU-relevant weights for tools/price_mix.py).  Writes gpurun_out/r04_wave_stats.json."""
 import json, os, sys
 sys.path.insert(0, os.getcwd())
 import torch
@@ -17,5 +17,5 @@ for name, fn, kw, spp, depth in (("cornell-box", scenes.cornell_box, {}, 64, 20)
                                                    inner_rounds_per_64_rays=64 * c["inner_rounds"] / r, leaf_rounds_per_64_rays=64 * c["leaf_rounds"] / r,
                                                    passes_per_64_rays=64 * c["refills"] / r, node_round_lane_utilisation=c["node_fetches"] / max(1, 64 * c["inner_rounds"]))
     del sc
-json.dump(out, open("gpurun_out/r03_wave_stats.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r04_wave_stats.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
