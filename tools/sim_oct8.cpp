@@ -258,7 +258,9 @@ struct Stats {
     int max_stack = 0;
 };
 
-enum Order { SORTED, OCTANT, OCT_CHILD, OCT_GROUP };
+enum Order { SORTED, OCTANT, OCT_CHILD, OCT_GROUP, SORTED_CULL };
+// SORTED_CULL: the product's scheme with the child's entry distance kept beside its ref: a popped child whose entry distance lies
+// beyond the closest hit found meanwhile is dropped without a visit.
 // OCT_CHILD: octant order, one stack entry per hit child (the product's stack, no sort), no re-test at pop.
 // OCT_GROUP: a node's hit LEAVES are entered first (one entry each), then its hit inner children from ONE group entry in octant
 // order; no re-test at pop (the entry carries no box).
@@ -269,7 +271,7 @@ static Stats run(const std::vector<WNode>& nodes, int node_bytes, Order order, c
     Stats st;
     const uint64_t tri_base = 1ULL << 40;
     std::vector<std::pair<float, int32_t>> hitk;
-    struct Entry { int32_t ref; uint32_t mask; }; // sorted scheme: one child per entry (mask unused); octant scheme: node + remaining hit slots
+    struct Entry { int32_t ref; uint32_t mask; float tn = 0.f; }; // sorted scheme: one child per entry (mask unused); octant scheme: node + remaining hit slots
     std::vector<Entry> stack;
     double stack_sum = 0, stack_samples = 0;
     for (size_t ri = 0; ri < rays.size(); ++ri) {
@@ -318,9 +320,9 @@ static Stats run(const std::vector<WNode>& nodes, int node_bytes, Order order, c
                         mask |= 1u << i;
                     }
                 }
-                if (order == SORTED) {
+                if (order == SORTED || order == SORTED_CULL) {
                     std::sort(hitk.begin(), hitk.end(), [](auto& x, auto& y) { return x.first < y.first; });
-                    for (size_t i = hitk.size(); i-- > 1;) stack.push_back({hitk[i].second, 0});
+                    for (size_t i = hitk.size(); i-- > 1;) stack.push_back({hitk[i].second, 0, hitk[i].first});
                     cur = hitk.empty() ? (int32_t)0x80000000 : hitk[0].second;
                 } else if (order == OCT_CHILD) {
                     // far to near by priority (slot ^ oct ascending = far first), nearest entered directly
@@ -357,7 +359,14 @@ static Stats run(const std::vector<WNode>& nodes, int node_bytes, Order order, c
             stack_samples += 1;
             if (cur == (int32_t)0x80000000) {
                 if (stack.empty()) break;
-                if (order == SORTED || order == OCT_CHILD || (order == OCT_GROUP && !(stack.back().mask & 0x100u))) {
+                if (order == SORTED_CULL) {
+                    cur = (int32_t)0x80000000;
+                    while (!stack.empty() && cur == (int32_t)0x80000000) {
+                        if ((double)stack.back().tn <= tbest) cur = stack.back().ref;
+                        stack.pop_back();
+                    }
+                    if (cur == (int32_t)0x80000000) break;
+                } else if (order == SORTED || order == OCT_CHILD || (order == OCT_GROUP && !(stack.back().mask & 0x100u))) {
                     cur = stack.back().ref;
                     stack.pop_back();
                 } else if (order == OCT_GROUP) {
@@ -512,6 +521,8 @@ int main(int argc, char** argv) {
         Variant h{"4-wide sorted, stack budget 40 (the product as shipped)", collapse(B.binary, 4, 40), 64, SORTED};
         quantise(h.nodes, B.grid_origin, B.grid_step, 16);
         vs.push_back(h);
+        Variant hc{"4-wide sorted, stack budget 40, entry distance kept: CULL AT POP", h.nodes, 64, SORTED_CULL};
+        vs.push_back(hc);
         Variant i6{"6-wide octant, entry per CHILD, stack budget 40", collapse(B.binary, 6, 40), 96, OCT_CHILD};
         quantise(i6.nodes, B.grid_origin, B.grid_step, 16);
         assign_octant_slots(i6.nodes);
