@@ -1,5 +1,5 @@
 """Whole-frame parity at the BASELINE configurations: every pixel of the fp64 GPU frame against the oracle's frame of the
-same (spp, depth, seed) — not only the rows bench.py samples.  Writes gpurun_out/r03_full_frame_parity.json.
+same (spp, depth, seed) — not only the rows bench.py samples.  Writes gpurun_out/r04_full_frame_parity.json.
 The oracle runs on the box's 16 host threads (about a minute per frame)."""
 import os as _os; _os.environ.setdefault("PRT_DEV_LIB", "1")  # the PRT_TUNE_* hooks exist in libprt_hip_dev.so only
 import json, os, sys, time
@@ -60,7 +60,7 @@ if os.environ.get("FF_VARIANTS") == "1":
     del os.environ["PRT_TUNE_SCRAMBLE"]
     res["pixel order scrambled"] = dict(cmp(img), equals_single_launch_bitwise=bool(np.array_equal(img, base)))
     print(json.dumps(res, indent=1), flush=True)
-    json.dump({"cornell-box spp 500 depth 20, every route": res}, open("gpurun_out/r03_full_frame_variants.json", "w"), indent=1)
+    json.dump({"cornell-box spp 500 depth 20, every route": res}, open("gpurun_out/r04_full_frame_variants.json", "w"), indent=1)
     raise SystemExit(0)
 for name, fn, kw, spp, depth in CONFIGS:
     data = fn(**kw)
@@ -79,4 +79,4 @@ for name, fn, kw, spp, depth in CONFIGS:
                  "width": cam.width, "height": cam.height}
     print(name, out[name], flush=True)
     del sc
-json.dump(out, open("gpurun_out/r03_full_frame_parity%s.json" % ("_full_spp" if os.environ.get("FF_FULL") == "1" else ""), "w"), indent=1)
+json.dump(out, open("gpurun_out/r04_full_frame_parity%s.json" % ("_full_spp" if os.environ.get("FF_FULL") == "1" else ""), "w"), indent=1)

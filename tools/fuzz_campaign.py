@@ -1,5 +1,5 @@
 """Parity campaign on random scenes (the generator of tests/test_gpu_parity.py::_random_scene): N seeds, frame against the
-oracle at 1e-9 per channel, every pixel; lists the seeds with pixels beyond it.  Writes gpurun_out/r03_fuzz_campaign.json."""
+oracle at 1e-9 per channel, every pixel; lists the seeds with pixels beyond it.  Writes gpurun_out/r04_fuzz_campaign.json."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -62,5 +62,5 @@ out = {"scenes": n, "first_seed": first, "spp": spp, "max_depth": depth, "pixels
        "random_rays": ray_tot, "rays_with_another_primitive_or_t_beyond_1e-12": ray_bad, "light_picks": pick_tot, "light_picks_differing": pick_bad,
        "camera_samples_compared_one_by_one": smp_tot, "samples_beyond_1e-9": smp_bad, "samples_with_another_path_signature": sig_bad,
        "seeds_with_differences": bad}
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r03_fuzz_campaign.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "r04_fuzz_campaign.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "seeds_with_differences"}), flush=True)
