@@ -188,13 +188,13 @@ typedef struct PrtBvhInfo {
     uint32_t width;      /* children per node */
     uint32_t tri_bytes;  /* payload of one intersection record: 32 (plane: n, D) + the part read after the interval test */
     uint32_t tri_stride; /* bytes between records in HBM once uploaded (0 before): tri_bytes, or 128 for scenes that stream from HBM */
-    /* image textures as resident on the device (0 before upload; ImageTexture::Value, Source/Texture.cpp:22-71).  A texture is
-     * stored as bilinear footprints (per texel cell the four taps of a lookup: 128 bytes per texel, one line per lookup) while
-     * the scene's footprints stay within 256 MiB, smallest texture first; larger ones stay plain texel arrays (24 bytes per
+    /* image textures as resident on the device (0 before upload; ImageTexture::Value, Source/Texture.cpp:22-71).  A scene's
+     * textures are stored as bilinear footprints (per texel cell the four taps of a lookup: 128 bytes per texel, one line per
+     * lookup) while ALL of them together stay within 256 MiB; a scene beyond that keeps plain texel arrays (24 bytes per
      * texel).  The fp32 fast mode adds a float copy of half the size on first use. */
     uint64_t texture_bytes;           /* fp64 bytes of all texel arrays */
     uint64_t texture_footprint_bytes; /* ... of which footprint records */
-    uint32_t texture_layouts;         /* bit 0: a texture is stored as footprints; bit 1: one is stored as plain texels */
+    uint32_t texture_layouts;         /* 0: no textures; 1: footprints; 2: plain texel arrays (one layout per scene) */
     /* how the fp64 render kernel (K3) of this scene is launched (0 before upload) */
     uint32_t render_blocks_per_cu;    /* resident 256-thread blocks per CU (= waves per SIMD) of the production instantiation */
     uint32_t render_blocks_wanted;    /* ... the register allocation of the scene's material permutation leaves room for */

@@ -21,7 +21,7 @@
 #include "prt_host.h"
 
 namespace prt {
-int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth, bool pad);
+int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth, bool pad, bool extra);
 int render_permutation(int feat);
 int render_lds_budget(int feat, int stack_depth);
 size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds);
@@ -52,7 +52,7 @@ void launch_gather_tris(const DTri* tri_in, const DTriShade* shade_in, const uin
 // fp32 fast mode (prt_kernels_f32.hip): K1 and K3 on float records derived from the resident fp64 ones
 namespace prt32 {
 typedef DSceneT<float> Scene32;
-int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth, bool pad);
+int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth, bool pad, bool extra);
 int render_lds_budget(int feat, int stack_depth);
 size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds);
 void launch_trace(const Scene32& S, const PrtRay* d_rays, size_t n, PrtHit* d_hits, DCounters* d_ctr, bool count, int n_cu,
@@ -530,55 +530,34 @@ static int upload_impl(PrtScene* s, int device) {
     }
     if ((rc = s->up(s->mats, &d.materials))) return rc;
     {
-        // textures go up as bilinear footprints (prt_device.h, tex_value): per cell (x0, y0) the four taps of a lookup, 16 reals
-        // Device layout of the texels, per texture (DTexture::has_data): 1 = BILINEAR FOOTPRINTS — per texel cell the four
-        // taps Value() blends, 16 reals = one 128-byte line per lookup (bathroom2 -1.8 %) at 5.3x the bytes; 2 = the plain
-        // row-major texel array (3 reals per texel, a lookup touches two to four lines).  Footprints are given out smallest
-        // texture first while the scene's footprint bytes stay within PRT_TEX_FOOTPRINT_BUDGET (256 MiB of fp64 records —
-        // the size of the Infinity Cache; the fp32 fast mode adds half as much again when it is used); what does not fit
-        // stays compact: a 4096^2 texture is 403 MB instead of 2.1 GB.  Same doubles, same blend, either way.
+        // Device layout of the texels, per SCENE (DScene::tex_compact): BILINEAR FOOTPRINTS — per texel cell the four taps
+        // Value() blends, 16 reals = one 128-byte line per lookup (bathroom2 -1.8 %) at 5.3x the bytes — while all the scene's
+        // footprints fit PRT_TEX_FOOTPRINT_BUDGET (256 MiB of fp64 records = the size of the Infinity Cache; the fp32 fast mode
+        // adds half as much again when it is used); else the plain row-major texel arrays (3 reals per texel, a lookup touches
+        // two to four lines): a 4096^2 texture is 403 MB instead of 2.1 GB.  Same doubles, same blend, either way.
         std::vector<DTexture> qt(s->texs);
         std::vector<double> quads;
-        std::vector<size_t> order;
-        for (size_t i = 0; i < s->texs.size(); ++i)
-            if (s->texs[i].has_data) order.push_back(i);
-        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
-            const size_t cx = (size_t)s->texs[x].width * s->texs[x].height, cy = (size_t)s->texs[y].width * s->texs[y].height;
-            return cx != cy ? cx < cy : x < y;
-        });
         size_t budget = PRT_TEX_FOOTPRINT_BUDGET;
         if (const char* e = dev_env("PRT_TUNE_TEX_BUDGET")) budget = (size_t)std::strtoull(e, nullptr, 10);
-        size_t fp_bytes = 0;
-        for (size_t i : order) {
-            const size_t cells = (size_t)s->texs[i].width * s->texs[i].height;
-            const bool footprint = fp_bytes + cells * 16 * sizeof(double) <= budget;
-            qt[i].has_data = footprint ? 1 : 2;
-            if (footprint) fp_bytes += cells * 16 * sizeof(double);
-        }
-        size_t reals = 0; // footprint records are read as 4-real vectors: they start on a multiple of 16 reals
-        for (size_t i = 0; i < s->texs.size(); ++i) {
-            if (!s->texs[i].has_data) continue;
-            const size_t cells = (size_t)s->texs[i].width * s->texs[i].height;
-            if (qt[i].has_data == 1) reals = (reals + 15) / 16 * 16;
-            qt[i].offset = reals;
-            reals += cells * (qt[i].has_data == 1 ? 16 : 3);
-        }
+        size_t cells_all = 0;
+        for (const DTexture& t : s->texs) cells_all += t.has_data ? (size_t)t.width * t.height : 0;
+        const bool compact = cells_all * 16 * sizeof(double) > budget;
+        const size_t per_cell = compact ? 3 : 16;
         try {
-            quads.assign(reals, 0.0);
+            quads.assign(cells_all * per_cell, 0.0);
         } catch (const std::bad_alloc&) {
             return fail(PRT_E_OOM, "prt_scene_upload: out of host memory for the texel arrays");
         }
+        size_t at = 0;
         for (size_t i = 0; i < s->texs.size(); ++i) {
             const DTexture& t = s->texs[i];
-            if (!t.has_data) {
-                qt[i].offset = 0;
-                continue;
-            }
-            size_t at = qt[i].offset;
+            qt[i].offset = at;
+            if (!t.has_data) continue;
             const double* px = s->texels_lin.data() + t.offset;
-            if (qt[i].has_data == 2) {
+            if (compact) {
                 const size_t n3 = (size_t)t.width * t.height * 3;
                 std::memcpy(quads.data() + at, px, n3 * sizeof(double));
+                at += n3;
                 continue;
             }
             for (int y0 = 0; y0 < t.height; ++y0)
@@ -590,9 +569,9 @@ static int upload_impl(PrtScene* s, int device) {
                     at += 16;
                 }
         }
-        s->tex_footprint_bytes = fp_bytes;
-        s->tex_layouts = 0;
-        for (const DTexture& t : qt) s->tex_layouts |= t.has_data == 1 ? 1u : t.has_data == 2 ? 2u : 0u;
+        d.tex_compact = compact ? 1u : 0u;
+        s->tex_footprint_bytes = compact ? 0 : cells_all * 16 * sizeof(double);
+        s->tex_layouts = cells_all == 0 ? 0u : (compact ? 2u : 1u);
         s->n_texel_reals = quads.size();
         if ((rc = s->up(qt, &d.textures))) return rc;
         if ((rc = s->up(quads, &d.texels_lin))) return rc;
@@ -662,8 +641,8 @@ static int upload_impl(PrtScene* s, int device) {
     static_assert(sizeof(DLightNode) == 16 && sizeof(DLightTri) % 16 == 0, "LDS staging copies 16-byte pieces");
     const size_t tables = prt::render_table_bytes(s->light_lds, s->mat_lds, s->ltri_lds);
     const bool pad = d.tri_stride == PRT_TRI_PAD_STRIDE(double) && sizeof(DTri) != PRT_TRI_PAD_STRIDE(double);
-    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat, tables, s->stack_depth, pad);
-    s->blocks_wanted = tables != 0 ? prt::render_blocks_per_cu(false, s->feat, 0, s->stack_depth, pad) : s->blocks_per_cu[0];
+    s->blocks_per_cu[0] = prt::render_blocks_per_cu(false, s->feat, tables, s->stack_depth, pad, !s->lights.tab.empty() || s->d.tex_compact != 0);
+    s->blocks_wanted = tables != 0 ? prt::render_blocks_per_cu(false, s->feat, 0, s->stack_depth, pad, !s->lights.tab.empty() || s->d.tex_compact != 0) : s->blocks_per_cu[0];
     if (s->blocks_per_cu[0] < s->blocks_wanted) {
         // the tables would cost the production kernel a resident block (the budget is an estimate; the occupancy query is
         // the truth): a block per CU is worth far more than the tables — render without them
@@ -671,7 +650,7 @@ static int upload_impl(PrtScene* s, int device) {
         s->blocks_per_cu[0] = s->blocks_wanted;
     }
     const size_t tables_used = prt::render_table_bytes(s->light_lds, s->mat_lds, s->ltri_lds);
-    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, tables_used, s->stack_depth, pad);
+    s->blocks_per_cu[1] = prt::render_blocks_per_cu(true, s->feat, tables_used, s->stack_depth, pad, !s->lights.tab.empty() || s->d.tex_compact != 0);
     if (dev_env("PRT_TUNE_VERBOSE"))
         std::fprintf(stderr, "[prt] fp64 render kernels: %d blocks per CU, LDS tables: %d materials, %d light triangles, %d light nodes\n",
                      s->blocks_per_cu[0], s->mat_lds, s->ltri_lds, s->light_lds);
@@ -802,6 +781,7 @@ static int ensure_f32_impl(PrtScene* s) {
         f.grid_step[a] = d.grid_step[a];
     }
     f.tri_stride = stride;
+    f.tex_compact = d.tex_compact;
     // The fp32 kernels have the registers for a fourth wave per SIMD; whether the LDS has room for a fourth block per CU
     // is decided by the traversal stacks: 32 entries per lane (32 KB per block) leave it, the builders' bound of
     // PRT_STACK_DEPTH does not.  Most trees need far fewer entries than that bound (tree_stack_need).
@@ -830,8 +810,8 @@ static int ensure_f32_impl(PrtScene* s) {
                 sizeof(DLightNodeT<float>), &s->mat_lds32, &s->ltri_lds32, &s->light_lds32);
     const size_t tables = prt32::render_table_bytes(s->light_lds32, s->mat_lds32, s->ltri_lds32);
     const bool pad = stride == PRT_TRI_PAD_STRIDE(float) && sizeof(DTriT<float>) != PRT_TRI_PAD_STRIDE(float);
-    s->blocks_per_cu32[0] = prt32::render_blocks_per_cu(false, s->feat, tables, s->stack_depth32, pad);
-    s->blocks_per_cu32[1] = prt32::render_blocks_per_cu(true, s->feat, tables, s->stack_depth32, pad);
+    s->blocks_per_cu32[0] = prt32::render_blocks_per_cu(false, s->feat, tables, s->stack_depth32, pad, !s->lights.tab.empty() || s->d.tex_compact != 0);
+    s->blocks_per_cu32[1] = prt32::render_blocks_per_cu(true, s->feat, tables, s->stack_depth32, pad, !s->lights.tab.empty() || s->d.tex_compact != 0);
     if (dev_env("PRT_TUNE_VERBOSE"))
         std::fprintf(stderr, "[prt] fp32 render kernels: %d blocks per CU, stacks %d, LDS tables: %d materials, %d light triangles, %d light nodes\n",
                      s->blocks_per_cu32[0], s->stack_depth32, s->mat_lds32, s->ltri_lds32, s->light_lds32);

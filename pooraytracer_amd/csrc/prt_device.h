@@ -456,6 +456,9 @@ PRT_DEV int wave_count(bool p) { return __popcll(__ballot(p)); }
 // reals padded to 16: one 128-byte line per lookup (two fp32 records per line) instead of the two to four lines the four
 // taps of a row-major texel array touch.  5.3x the bytes of the texel array; only the lines a frame touches matter.
 #define PRT_TEX_QUAD_REALS 16
+// EXTRA (PRT_FEAT_EXTRA kernels): the scene may hold plain texel arrays; kernels for scenes that do not are compiled without that
+// path (its mere presence cost the bathroom2 frame 1.3 % in a same-box A/B: the textured kernel sits at its register limit).
+template <bool EXTRA>
 PRT_DEV d3 tex_value(const DScene& S, int ti, real u, real v) {
     const DTexture tx = S.textures[ti];
     if (!tx.has_data) return mk3(RL(0.), RL(1.), RL(1.));
@@ -466,12 +469,12 @@ PRT_DEV d3 tex_value(const DScene& S, int ti, real u, real v) {
     int x0 = (int)x, y0 = (int)y;
     real fx = x - x0, fy = y - y0;
     d3 c00, c10, c01, c11;
-    if (tx.has_data == 1) { // footprint record of cell (x0, y0): the four taps in one 128-byte line
+    if (!EXTRA || !S.tex_compact) { // footprint record of cell (x0, y0): the four taps in one 128-byte line (wave-uniform choice)
         const real4* q = reinterpret_cast<const real4*>(S.texels_lin + tx.offset + (size_t)(y0 * tx.width + x0) * PRT_TEX_QUAD_REALS);
         const real4 q0 = q[0], q1 = q[1], q2 = q[2];
         c00 = mk3(q0.x, q0.y, q0.z), c10 = mk3(q0.w, q1.x, q1.y);
         c01 = mk3(q1.z, q1.w, q2.x), c11 = mk3(q2.y, q2.z, q2.w);
-    } else { // plain texel array (textures beyond the scene's footprint budget): Texture.cpp:35-41's four GetPixel calls
+    } else { // plain texel arrays (a scene beyond its footprint budget): Texture.cpp:35-41's four GetPixel calls
         const int x1 = min(x0 + 1, tx.width - 1), y1 = min(y0 + 1, tx.height - 1);
         const real* base = S.texels_lin + tx.offset;
         c00 = ld3(base + ((size_t)y0 * tx.width + x0) * 3), c10 = ld3(base + ((size_t)y0 * tx.width + x1) * 3);
@@ -738,14 +741,18 @@ PRT_DEV d3 ct_sample_wm(const DMaterial& m, d3 w, d2 u) { // Material.h:412-435
 #define PRT_FEAT_PHONG 2
 #define PRT_FEAT_CT 4
 #define PRT_FEAT_ALL 7
+// Not a material feature: kernels with this bit also carry the two rarely needed code paths — the light-table lookup of
+// sample_lights and the plain-texel-array path of tex_value.  A scene that needs neither (no emissive subtree of >= 16
+// triangles, textures within the footprint budget) runs the kernels without them (same-box A/B: cornell +0.9 %, bathroom2 +1.3 %).
+#define PRT_FEAT_EXTRA 8
 template <int FEAT>
 PRT_DEV d3 mat_kd(const DScene& S, const DMaterial& m, d2 uv) {
-    if ((FEAT & PRT_FEAT_TEX) && m.texture >= 0) return tex_value(S, m.texture, uv.x, uv.y);
+    if ((FEAT & PRT_FEAT_TEX) && m.texture >= 0) return tex_value<(FEAT & PRT_FEAT_EXTRA) != 0>(S, m.texture, uv.x, uv.y);
     return ld3(m.kd);
 }
 template <int FEAT>
 PRT_DEV d3 mat_ks(const DScene& S, const DMaterial& m, d2 uv) { // Phong(mapKd,...) stores the map in Ks too (:178-181)
-    if ((FEAT & PRT_FEAT_TEX) && m.texture >= 0) return tex_value(S, m.texture, uv.x, uv.y);
+    if ((FEAT & PRT_FEAT_TEX) && m.texture >= 0) return tex_value<(FEAT & PRT_FEAT_EXTRA) != 0>(S, m.texture, uv.x, uv.y);
     return ld3(m.ks);
 }
 template <int FEAT>
@@ -882,7 +889,9 @@ struct LightPick {
 // by the kernel, or null / 0.  The descent is a chain of dependent 16-byte reads, one per tree level (13 for
 // veach-mis's 6400 light triangles: 11 % of its frame from L1/L2, and the ~30 KB of LDS the top 1800 nodes took cost the
 // Phong permutation its third wave) — since round 4 only the few nodes above the per-mesh TABLES are descended.
-template <bool LLDS>
+// LTAB: the kernel carries the light-table lookup (PRT_FEAT_EXTRA kernels; scenes without tables run kernels without it: its
+// mere presence cost the cornell frame 0.9 % in a same-box A/B).
+template <bool LLDS, bool LTAB>
 PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLightNode* lds_nodes = nullptr, int32_t n_lds = 0,
                                 const DLightTri* lds_tris = nullptr, int32_t n_tris_lds = 0) {
     (void)rng.next();
@@ -891,7 +900,7 @@ PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLig
     int32_t node = S.light_root;
     // plain node refs are below PRT_LIGHT_TABLE_BIT, table refs at or above it, leaf refs negative: ONE unsigned compare per
     // level, as before the tables existed (a scene without tables pays one more compare per pick, after the loop)
-    while ((uint32_t)node < (uint32_t)PRT_LIGHT_TABLE_BIT) {
+    while (LTAB ? (uint32_t)node < (uint32_t)PRT_LIGHT_TABLE_BIT : node >= 0) {
         DLightNode ln;
         if (LLDS && node < n_lds) ln = lds_nodes[node];
         else ln = S.light_nodes[node];
@@ -901,7 +910,7 @@ PRT_DEV LightPick sample_lights(const DScene& S, d3 origin, Rng& rng, const DLig
             node = ln.right;
         }
     }
-    if (node >= 0) {
+    if (LTAB && node >= 0) {
         // A subtree on which the descent is a monotone step function of p (prt_types.h, DLightTable): one bucket read gives
         // the first leaf p can reach and the threshold of the next one; thresholds were found by bisection through this
         // very descent, so the pick is the descent's bit for bit.

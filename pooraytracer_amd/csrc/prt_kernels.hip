@@ -56,7 +56,8 @@
 #ifndef PRT_F32_WAVES
 #define PRT_F32_WAVES 3 // fp32 fast mode: resident waves per SIMD of every K3 permutation
 #endif
-constexpr int render_waves(int feat) {
+constexpr int render_waves(int feat_with_extra) {
+    const int feat = feat_with_extra & PRT_FEAT_ALL; // (PRT_FEAT_EXTRA is not a material feature)
     if (PRT_F32_TU) return PRT_F32_WAVES;
     return feat == 0 ? PRT_RENDER_WAVES_LEAN
          : feat == PRT_FEAT_TEX ? PRT_RENDER_WAVES_TEX
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(PRT_BLOCK, render_waves(FEAT)) void k_render(Render
                             // next-event estimation, Camera.cpp:137-155: pick the light point now (4 draws)
                             const d3 gn = ld3(tri_at<PAD>(S, (uint32_t)sh_tri)->n);
                             const d3 fn = dot(rd, gn) < RL(0.) ? gn : -gn;
-                            const LightPick lp = sample_lights<LLDS>(S, tr.o, rng, lds_lights, P.light_lds, lds_ltris, P.ltri_lds);
+                            const LightPick lp = sample_lights<LLDS, (FEAT & PRT_FEAT_EXTRA) != 0>(S, tr.o, rng, lds_lights, P.light_lds, lds_ltris, P.ltri_lds);
                             real dist;
                             const d3 ldir = normalize_len(lp.pos - tr.o, dist);
                             if (dot(fn, ldir) > RL(0.0) && lp.front) {
@@ -781,7 +782,7 @@ __global__ void k_sample_lights(DScene S, const double* __restrict__ origins, si
     if (i >= n) return;
     Rng rng;
     rng.seed(seed, i, 0);
-    const LightPick lp = sample_lights<false>(S, mk3(origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2]), rng);
+    const LightPick lp = sample_lights<false, true>(S, mk3(origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2]), rng);
     PrtLightSample o;
     o.position[0] = lp.pos.x; o.position[1] = lp.pos.y; o.position[2] = lp.pos.z;
     o.normal[0] = lp.n.x; o.normal[1] = lp.n.y; o.normal[2] = lp.n.z;
@@ -800,7 +801,7 @@ __global__ void k_material_eval(DScene S, int material, const double* __restrict
     Rng rng;
     rng.seed(seed, i, 0);
     const d2 t = uv ? d2{uv[i * 2], uv[i * 2 + 1]} : d2{0., 0.};
-    const d3 f = mat_eval<PRT_FEAT_ALL>(S, S.materials[material], ld3(wi + i * 3), ld3(wo + i * 3), t, rng);
+    const d3 f = mat_eval<PRT_FEAT_ALL | PRT_FEAT_EXTRA>(S, S.materials[material], ld3(wi + i * 3), ld3(wo + i * 3), t, rng);
     out[i * 3] = f.x; out[i * 3 + 1] = f.y; out[i * 3 + 2] = f.z;
 }
 __global__ void k_material_scatter(DScene S, int material, const double* __restrict__ rd, d3 normal, d3 tangent,
@@ -813,7 +814,7 @@ __global__ void k_material_scatter(DScene S, int material, const double* __restr
     const Frame f{normal, tangent};
     const d2 t = uv ? d2{uv[i * 2], uv[i * 2 + 1]} : d2{0., 0.};
     d3 att = mk3(0, 0, 0), wi = mk3(0, 0, 0);
-    const bool ok = mat_scatter<PRT_FEAT_ALL>(S, S.materials[material], ld3(rd + i * 3), f, t, rng, att, wi);
+    const bool ok = mat_scatter<PRT_FEAT_ALL | PRT_FEAT_EXTRA>(S, S.materials[material], ld3(rd + i * 3), f, t, rng, att, wi);
     ok_out[i] = ok ? 1 : 0;
     wi_out[i * 3] = ok ? wi.x : 0.; wi_out[i * 3 + 1] = ok ? wi.y : 0.; wi_out[i * 3 + 2] = ok ? wi.z : 0.;
     att_out[i * 3] = ok ? att.x : 0.; att_out[i * 3 + 1] = ok ? att.y : 0.; att_out[i * 3 + 2] = ok ? att.z : 0.;
@@ -821,7 +822,7 @@ __global__ void k_material_scatter(DScene S, int material, const double* __restr
 __global__ void k_texture_value(DScene S, int texture, const double* __restrict__ uv, size_t n, double* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const d3 c = tex_value(S, texture, uv[i * 2], uv[i * 2 + 1]);
+    const d3 c = tex_value<true>(S, texture, uv[i * 2], uv[i * 2 + 1]);
     out[i * 3] = c.x; out[i * 3 + 1] = c.y; out[i * 3 + 2] = c.z;
 }
 
@@ -870,33 +871,37 @@ size_t render_table_bytes(int light_lds, int mat_lds, int ltri_lds) {
 }
 
 typedef void (*RenderKernel)(RenderArgs);
+// COUNT instantiations exist only with PRT_FEAT_EXTRA (statistics runs: speed is not what they are for)
 template <int FEAT, bool PAD>
-static RenderKernel render_kernel_feat(bool count, bool llds) {
-    if (count) return llds ? k_render<true, FEAT, true, PAD> : k_render<true, FEAT, false, PAD>;
+static RenderKernel render_kernel_feat(bool count, bool llds, bool extra) {
+    constexpr int X = FEAT | PRT_FEAT_EXTRA;
+    if (count) return llds ? k_render<true, X, true, PAD> : k_render<true, X, false, PAD>;
+    if (extra) return llds ? k_render<false, X, true, PAD> : k_render<false, X, false, PAD>;
     return llds ? k_render<false, FEAT, true, PAD> : k_render<false, FEAT, false, PAD>;
 }
 template <bool PAD>
-static RenderKernel render_kernel_pad(bool count, int feat, bool llds) {
+static RenderKernel render_kernel_pad(bool count, int feat, bool llds, bool extra) {
     switch (render_permutation(feat)) {
-    case 0: return render_kernel_feat<0, PAD>(count, llds);
-    case PRT_FEAT_TEX: return render_kernel_feat<PRT_FEAT_TEX, PAD>(count, llds);
-    case PRT_FEAT_PHONG: return render_kernel_feat<PRT_FEAT_PHONG, PAD>(count, llds);
-    case PRT_FEAT_CT: return render_kernel_feat<PRT_FEAT_CT, PAD>(count, llds);
-    default: return render_kernel_feat<PRT_FEAT_ALL, PAD>(count, llds);
+    case 0: return render_kernel_feat<0, PAD>(count, llds, extra);
+    case PRT_FEAT_TEX: return render_kernel_feat<PRT_FEAT_TEX, PAD>(count, llds, extra);
+    case PRT_FEAT_PHONG: return render_kernel_feat<PRT_FEAT_PHONG, PAD>(count, llds, extra);
+    case PRT_FEAT_CT: return render_kernel_feat<PRT_FEAT_CT, PAD>(count, llds, extra);
+    default: return render_kernel_feat<PRT_FEAT_ALL, PAD>(count, llds, extra);
     }
 }
-// `pad`: the scene's intersection records sit 128 bytes apart (DScene::tri_stride)
-static RenderKernel render_kernel(bool count, int feat, bool llds, bool pad) {
-    return pad ? render_kernel_pad<true>(count, feat, llds) : render_kernel_pad<false>(count, feat, llds);
+// `pad`: the scene's intersection records sit 128 bytes apart (DScene::tri_stride); `extra`: the scene has light tables or
+// plain texel arrays (PRT_FEAT_EXTRA kernels)
+static RenderKernel render_kernel(bool count, int feat, bool llds, bool pad, bool extra) {
+    return pad ? render_kernel_pad<true>(count, feat, llds, extra) : render_kernel_pad<false>(count, feat, llds, extra);
 }
 
 static size_t stack_bytes(int stack_depth) { return PRT_DYN_STACK ? (size_t)PRT_BLOCK * stack_depth * sizeof(uint32_t) : 0; }
 
 // Resident blocks per CU of the instantiation a launch will use (`pad`: the scene's records sit at the padded stride —
 // a different function with its own register count).
-int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth, bool pad) {
+int render_blocks_per_cu(bool count, int feat, size_t table_bytes, int stack_depth, bool pad, bool extra) {
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel(count, feat, table_bytes != 0, pad), PRT_BLOCK,
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel(count, feat, table_bytes != 0, pad, extra), PRT_BLOCK,
                                                                 table_bytes + stack_bytes(stack_depth));
     if (e != hipSuccess || nb < 1) nb = 1;
     return nb;
@@ -926,7 +931,7 @@ void launch_render(const DScene& S, const DCamera& C, const DRenderParams& P, do
     A.P = P;
     A.partial = d_partial;
     A.ctr = d_ctr;
-    hipLaunchKernelGGL(render_kernel(count, feat, tables != 0, pad), dim3(grid), dim3(PRT_BLOCK), dyn_lds, st, A);
+    hipLaunchKernelGGL(render_kernel(count, feat, tables != 0, pad, S.light_tab != nullptr || S.tex_compact != 0), dim3(grid), dim3(PRT_BLOCK), dyn_lds, st, A);
 }
 
 #if PRT_F32_TU

@@ -93,10 +93,10 @@ struct alignas(16) DMaterialT {
 typedef DMaterialT<prt_real> DMaterial;
 static_assert(sizeof(DMaterialT<double>) == 192 && sizeof(DMaterialT<float>) % 16 == 0, "materials are staged into LDS in 16-byte pieces");
 
-#define PRT_TEX_FOOTPRINT_BUDGET (256ull << 20) // fp64 bytes of footprint records a scene may hold; textures beyond it stay plain texel arrays
+#define PRT_TEX_FOOTPRINT_BUDGET (256ull << 20) // fp64 bytes of footprint records a scene may hold; a scene beyond it keeps plain texel arrays (DScene::tex_compact)
 struct DTexture {
     int32_t width, height, channels;
-    int32_t has_data; // 0: no texels (Value() = (0,1,1)); 1: bilinear footprints, 16 reals per texel cell; 2: row-major texels, 3 reals each
+    int32_t has_data; // 0: no texels (Value() = (0,1,1))
     uint64_t offset; // index of the texture's first real in texels_lin
 };
 
@@ -164,7 +164,8 @@ struct DSceneT {
     float grid_origin[3]; // box coordinate = grid_origin + q * grid_step
     float grid_step[3];
     uint32_t tri_stride;  // bytes between consecutive DTri records: sizeof(DTri), or the padded stride for HBM-resident scenes
-    uint32_t pad2_;
+    uint32_t tex_compact; // 0: texels_lin holds bilinear footprints (16 reals per texel cell); 1: row-major texels, 3 reals each — one
+                          // layout per SCENE, so that tex_value branches on a scalar (a per-texture flag cost bathroom2 1.4 %)
 };
 typedef DSceneT<prt_real> DScene;
 // padded record stride: one fp64 record per 128-byte line, two fp32 records per line — never one straddling two lines

@@ -799,8 +799,9 @@ def test_random_scenes_against_the_oracle(gpu, seed):
 def test_render_samples_hook_matches_the_oracle_per_sample(gpu, scene_fn, depth):
     """prt_render_samples: RayColor of single samples through K3 itself, with the path's signature (triangles hit, NEE /
     visibility / roulette / Scatter decisions per vertex).  Per (pixel, sample): the same radiance as the oracle to 1e-9 and
-    the same signature; the production instantiation and the counting one give the same numbers bit for bit; a frame is
-    the mean of its samples."""
+    the same signature; the production instantiation and the counting one give the same numbers (to rounding: since round 4 the
+    counting kernels are the PRT_FEAT_EXTRA compilation, which may contract its multiply-adds differently); a frame is the mean
+    of its samples."""
     data = scene_fn()
     cam = data.camera
     sc = api.Scene(data).upload(gpu)
@@ -810,7 +811,7 @@ def test_render_samples_hook_matches_the_oracle_per_sample(gpu, scene_fn, depth)
     spp = 70  # more than one launch of PRT_MAX_CHUNKS samples
     g, gt = sc.render_samples(px, spp=spp, max_depth=depth, seed=4, trace=True)
     gp = sc.render_samples(px, spp=spp, max_depth=depth, seed=4)
-    assert np.array_equal(g, gp)
+    assert (np.abs(g - gp) <= 1e-12 * np.maximum(1.0, np.abs(gp))).all()
     o, ot = orc.render_samples(px, spp=spp, max_depth=depth, seed=4, trace=True)
     rel = np.abs(g - o) / np.maximum(1.0, np.abs(o))
     same = (gt == ot).all(-1)
@@ -821,7 +822,7 @@ def test_render_samples_hook_matches_the_oracle_per_sample(gpu, scene_fn, depth)
     assert (gt[..., 0] >= 1).all() and (gt[..., 0] <= depth + 1).all() and gt[..., 0].max() > 3
     # sub-ranges address the same streams
     g2 = sc.render_samples(px[:5], spp=spp, max_depth=depth, seed=4, sample_begin=17, sample_count=9)
-    assert np.array_equal(g2, g[:5, 17:26])
+    assert np.array_equal(g2, gp[:5, 17:26])  # (gp: the production kernel, like g2; g came from the counting compilation)
     # a frame's pixel is the mean of its samples (summed in another order: rounding only)
     img = sc.render(spp=spp, max_depth=depth, seed=4)
     want = g.mean(axis=1)
@@ -966,9 +967,9 @@ def test_whole_frame_equals_the_oracle_on_every_pixel(gpu, name, factory, depth)
 
 def test_texture_footprints_have_a_ceiling(gpu):
     """VERDICT r3 #6 (ImageTexture::Value, Source/Texture.cpp:22-71): textures are stored as bilinear footprints (128 bytes per
-    texel, one line per lookup) only while a scene's footprints stay within 256 MiB, smallest texture first; what does not
-    fit stays a plain texel array (24 bytes per texel).  A 4096^2 map next to a 512^2 one: the small one gets footprints, the
-    large one does not, the scene uploads in < 0.5 GB of texels instead of 2.2 GB, and the frame equals the oracle's."""
+    texel, one line per lookup) only while ALL of a scene's footprints stay within 256 MiB; a scene beyond that keeps plain
+    texel arrays (24 bytes per texel) — one layout per scene, so the kernel's choice is a scalar branch.  A 4096^2 map next to
+    a 512^2 one: the scene uploads in < 0.5 GB of texels instead of 2.2 GB, and the frame equals the oracle's."""
     import copy
     data = copy.copy(scenes.bathroom(96, 54, detail=0.15))
     big = np.tile(data.textures[0], (8, 8, 1))                   # 4096 x 4096 x 3
@@ -976,9 +977,8 @@ def test_texture_footprints_have_a_ceiling(gpu):
     data.textures = [big, data.textures[1]]
     sc = api.Scene(data).upload(gpu)
     info = sc.bvh_info()
-    assert info["texture_layouts"] == 3                                           # both layouts in use
-    assert info["texture_footprint_bytes"] == 512 * 512 * 128                     # the small texture
-    assert info["texture_bytes"] == 512 * 512 * 128 + 4096 * 4096 * 24 < 0.5e9    # (as footprints: 2.2 GB)
+    assert info["texture_layouts"] == 2 and info["texture_footprint_bytes"] == 0          # plain texel arrays
+    assert info["texture_bytes"] == (512 * 512 + 4096 * 4096) * 24 < 0.5e9                # (as footprints: 2.2 GB)
     img = sc.render(spp=4, max_depth=6, seed=5)
     ref, _ = oracle.Oracle(data).render(spp=4, max_depth=6, seed=5, nthreads=8)
     compare_images(img, ref)
@@ -986,14 +986,16 @@ def test_texture_footprints_have_a_ceiling(gpu):
     img32 = sc.render(spp=4, max_depth=6, seed=5, precision=1)
     assert np.isfinite(img32).all() and abs(img32.mean() - ref.mean()) <= 2e-3 * ref.mean()
     sc.close()
-    # the stand-in scenes are far below the ceiling: footprints only, as measured in DESIGN.md
+    # the stand-in scenes are far below the ceiling: footprints, as measured in DESIGN.md
     small = api.Scene(scenes.bathroom(96, 54, detail=0.15)).upload(gpu)
     assert small.bvh_info()["texture_layouts"] == 1 and small.bvh_info()["texture_bytes"] == 2 * 512 * 512 * 128
+    assert small.bvh_info()["texture_footprint_bytes"] == 2 * 512 * 512 * 128
 
 
 def test_texture_layouts_give_the_same_frame(gpu, dev_lib, monkeypatch):
     """Same doubles, same blend: with the footprint budget forced to 0 (dev-hooks library) every texture stays a plain texel
-    array and the frame is the footprint build's bit for bit."""
+    array; the texture lookups are the footprint build's bit for bit (same kernel), the frame to rounding (the scene then runs
+    the PRT_FEAT_EXTRA compilation of K3: another kernel, other FMA contractions)."""
     data = scenes.bathroom(96, 54, detail=0.15)
     a = api.Scene(data).upload(gpu)
     assert a.bvh_info()["texture_layouts"] == 1
@@ -1001,7 +1003,8 @@ def test_texture_layouts_give_the_same_frame(gpu, dev_lib, monkeypatch):
     b = api.Scene(data).upload(gpu)
     assert b.bvh_info()["texture_layouts"] == 2 and b.bvh_info()["texture_footprint_bytes"] == 0
     kw = dict(spp=4, max_depth=6, seed=5)
-    assert np.array_equal(a.render(**kw), b.render(**kw))
+    ia, ib = a.render(**kw), b.render(**kw)
+    assert (np.abs(ia - ib) <= 1e-12 * np.maximum(1.0, np.abs(ib))).all()
     uv = np.random.default_rng(3).uniform(-0.2, 1.2, size=(4096, 2))
     assert np.array_equal(a.texture_value(0, uv), b.texture_value(0, uv))
 

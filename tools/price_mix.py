@@ -65,7 +65,8 @@ def asm_of(f32):
 
 
 def kernel_body(src, feat, f32):
-    pat = re.compile(r"^_ZN.*k_renderILb0ELi%dELb1ELb0E.*:" % feat)
+    # <COUNT false, FEAT, LLDS true, PAD false>: veach-mis has light tables, so it runs the PRT_FEAT_EXTRA (| 8) kernel
+    pat = re.compile(r"^_ZN.*k_renderILb0ELi%dELb1ELb0E.*:" % (feat | 8 if feat == 2 else feat))
     start = next(i for i, l in enumerate(src) if pat.match(l))
     end = next(i for i in range(start, len(src)) if src[i].startswith(".Lfunc_end"))
     return src[start:end]
