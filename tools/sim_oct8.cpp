@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <random>
 #include <string>
 #include <vector>
@@ -164,6 +165,113 @@ static std::vector<WNode> collapse(const std::vector<BuiltBVH::BinNode>& bin, in
         }
         for (int k = n.nk - 1; k >= 0; --k)
             if (bref[k] >= 0) todo.push_back({bref[k], n.ref[k], o.budget - (n.nk - 1)});
+        out[o.slot] = n;
+    }
+    return out;
+}
+
+
+// Cost-optimal collapse (Ylitie, Karras, Laine 2017, §3): minimise the summed surface area of the WIDE nodes — a visit costs a
+// SIMT kernel the same whatever the node holds, and the area is the probability of the visit.  c[n][i] = least cost of turning
+// the binary subtree n into a forest of at most i wide-tree roots (i = 1: a single wide node, or the binary leaf itself);
+// the children of a wide node rooted at n are a forest of `width` roots of n's two subtrees.  Leaves are the builder's.
+static std::vector<WNode> collapse_optimal(const std::vector<BuiltBVH::BinNode>& bin, int width) {
+    const size_t nb = bin.size();
+    auto box_area = [&](size_t i) { // area of binary node i = union of its two child boxes
+        WBox b;
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] = std::min(bin[i].lo[0][a], bin[i].lo[1][a]);
+            b.hi[a] = std::max(bin[i].hi[0][a], bin[i].hi[1][a]);
+        }
+        return area(b);
+    };
+    const int W = width;
+    std::vector<double> c(nb * (W + 1), 0.0);      // c[n * (W+1) + i], i = 1..W
+    std::vector<int8_t> split(nb * (W + 1), 0);    // forest of i roots: how many go to the left subtree (0 = "use i - 1")
+    auto cost = [&](int32_t ref, int i) -> double { return ref < 0 ? 0.0 : c[(size_t)ref * (W + 1) + std::min(i, W)]; };
+    for (size_t n = nb; n-- > 0;) { // children follow their parent in the pre-order array
+        const int32_t l = bin[n].ref[0], r = bin[n].ref[1];
+        auto distribute = [&](int j, int8_t& best_a) { // forest of j >= 2 roots over the two subtrees
+            double best = 1e300;
+            for (int a = 1; a < j; ++a) {
+                const double v = cost(l, a) + cost(r, j - a);
+                if (v < best) {
+                    best = v;
+                    best_a = (int8_t)a;
+                }
+            }
+            return best;
+        };
+        int8_t a1 = 1;
+        c[n * (W + 1) + 1] = box_area(n) + distribute(W, a1); // one wide node with up to W children
+        split[n * (W + 1) + 1] = a1;
+        for (int i = 2; i <= W; ++i) {
+            int8_t ai = 1;
+            const double d = distribute(i, ai);
+            if (d < c[n * (W + 1) + i - 1]) {
+                c[n * (W + 1) + i] = d;
+                split[n * (W + 1) + i] = ai;
+            } else {
+                c[n * (W + 1) + i] = c[n * (W + 1) + i - 1];
+                split[n * (W + 1) + i] = 0;
+            }
+        }
+    }
+    // emit: children of the wide node at binary node n = forest(n, W)
+    std::vector<WNode> out;
+    struct Kid { int32_t ref; WBox box; };
+    std::vector<Kid> kids;
+    // forest(ref with box, i): appends the roots
+    std::function<void(int32_t, const WBox&, int)> forest = [&](int32_t ref, const WBox& box, int i) {
+        if (ref < 0) {
+            kids.push_back({ref, box});
+            return;
+        }
+        i = std::min(i, W);
+        while (i > 1 && split[(size_t)ref * (W + 1) + i] == 0) --i;
+        if (i == 1) {
+            kids.push_back({ref, box}); // a wide node of its own
+            return;
+        }
+        const int a = split[(size_t)ref * (W + 1) + i];
+        WBox bl, br;
+        for (int x = 0; x < 3; ++x) {
+            bl.lo[x] = bin[ref].lo[0][x]; bl.hi[x] = bin[ref].hi[0][x];
+            br.lo[x] = bin[ref].lo[1][x]; br.hi[x] = bin[ref].hi[1][x];
+        }
+        forest(bin[ref].ref[0], bl, a);
+        forest(bin[ref].ref[1], br, i - a);
+    };
+    struct Open { int32_t bin; int32_t slot; };
+    std::vector<Open> todo;
+    out.emplace_back();
+    todo.push_back({0, 0});
+    while (!todo.empty()) {
+        const Open o = todo.back();
+        todo.pop_back();
+        kids.clear();
+        const int a = split[(size_t)o.bin * (W + 1) + 1];
+        WBox bl, br;
+        for (int x = 0; x < 3; ++x) {
+            bl.lo[x] = bin[o.bin].lo[0][x]; bl.hi[x] = bin[o.bin].hi[0][x];
+            br.lo[x] = bin[o.bin].lo[1][x]; br.hi[x] = bin[o.bin].hi[1][x];
+        }
+        forest(bin[o.bin].ref[0], bl, a);
+        forest(bin[o.bin].ref[1], br, W - a);
+        WNode n;
+        n.nk = (int)kids.size();
+        std::vector<Kid> mine = kids; // (forest() reuses `kids`)
+        for (int k = 0; k < n.nk; ++k) {
+            n.used[k] = true;
+            n.box[k] = mine[k].box;
+            if (mine[k].ref < 0) n.ref[k] = mine[k].ref;
+            else {
+                n.ref[k] = (int32_t)out.size();
+                out.emplace_back();
+            }
+        }
+        for (int k = n.nk - 1; k >= 0; --k)
+            if (mine[k].ref >= 0) todo.push_back({mine[k].ref, n.ref[k]});
         out[o.slot] = n;
     }
     return out;
@@ -523,6 +631,9 @@ int main(int argc, char** argv) {
         vs.push_back(h);
         Variant hc{"4-wide sorted, stack budget 40, entry distance kept: CULL AT POP", h.nodes, 64, SORTED_CULL};
         vs.push_back(hc);
+        Variant ho{"4-wide sorted, COST-OPTIMAL collapse (min summed node area)", collapse_optimal(B.binary, 4), 64, SORTED};
+        quantise(ho.nodes, B.grid_origin, B.grid_step, 16);
+        vs.push_back(ho);
         Variant i6{"6-wide octant, entry per CHILD, stack budget 40", collapse(B.binary, 6, 40), 96, OCT_CHILD};
         quantise(i6.nodes, B.grid_origin, B.grid_step, 16);
         assign_octant_slots(i6.nodes);
