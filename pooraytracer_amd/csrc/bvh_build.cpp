@@ -496,14 +496,26 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
         // wide-tree roots: c(n, 1) = area(n) + best split of four roots over n's two subtrees (n becomes a wide node),
         // c(n, i) = min(c(n, i - 1), best split of i roots over the two subtrees).  The builder's leaves stay leaves.  Against
         // the greedy largest-box rule: 20-28 % fewer nodes and, on random rays, -0.9 % (cornell) / -1.9 % (bathroom2) / -9.7 %
-        // (veach-mis) node visits (tools/sim_oct8.cpp).  The greedy collapse with its stack budget remains the fallback for
-        // trees whose optimal collapse could need more than PRT_STACK_DEPTH entries, and the rule of the 32-entry tree.
-        auto collapse_optimal = [&](std::vector<DNode>& nodes) -> uint32_t {
+        // (veach-mis) node visits (tools/sim_oct8.cpp).  The greedy collapse with its stack budget remains the rule of the 32-entry
+        // tree, of trees beyond two million binary nodes and of the GPU builder.
+        // The stack bound enters the programme as a LEVEL: a wide node at level L of the wide tree is entered with at most
+        // 3 L entries on the stack (every ancestor pushed at most three siblings), so a tree of at most (entries - 1) / 3 levels can
+        // never need more than `entries`: c(n, i, L) = least cost of a forest of at most i roots AT LEVEL L over
+        // the binary subtree n; a wide node at the last level may only have leaves below it.  (Conservative by up to two
+        // entries per level against the exact k - 1; a deep tree — bathroom2: 30 binary levels — still gets 13 wide ones.)
+        auto collapse_optimal = [&](int stack_entries, std::vector<DNode>& nodes) -> uint32_t {
             const size_t nb = fn.size();
             constexpr int W = 4;
-            std::vector<float> c(nb * (W + 1), 0.f);
-            std::vector<int8_t> split(nb * (W + 1), 0); // roots given to the left subtree; 0 = "same as with one root fewer"
-            auto cost = [&](int32_t ref, int i) -> float { return ref < 0 ? 0.f : c[(size_t)ref * (W + 1) + std::min(i, W)]; };
+            const int L = (stack_entries - 1) / 3; // level l < L: 3 l + 3 <= stack_entries
+            const float inf = std::numeric_limits<float>::infinity();
+            std::vector<float> c(nb * L * (W + 1), 0.f);
+            std::vector<int8_t> split(nb * L * (W + 1), 0); // roots given to the left subtree; 0 = "same as with one root fewer"
+            auto at = [&](size_t n_, int lev, int i) { return (n_ * L + (size_t)lev) * (W + 1) + (size_t)i; };
+            auto cost = [&](int32_t ref, int lev, int i) -> float {
+                if (ref < 0) return 0.f;           // a leaf costs no node visit, at any level
+                if (lev >= L) return inf;          // no wide node below the last level
+                return c[at((size_t)ref, lev, std::min(i, W))];
+            };
             for (size_t i = nb; i-- > 0;) { // children follow their parent in the pre-order array
                 const Kid k0 = kid_of(fn[i], 0), k1 = kid_of(fn[i], 1);
                 Kid u = k0;
@@ -511,32 +523,36 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
                     u.lo[a] = std::min(k0.lo[a], k1.lo[a]);
                     u.hi[a] = std::max(k0.hi[a], k1.hi[a]);
                 }
-                auto distribute = [&](int j, int8_t& best_a) {
-                    float best = std::numeric_limits<float>::infinity();
-                    for (int a = 1; a < j; ++a) {
-                        const float v = cost(k0.ref, a) + cost(k1.ref, j - a);
-                        if (v < best) {
-                            best = v;
-                            best_a = (int8_t)a;
+                const float au = area(u);
+                for (int lev = L - 1; lev >= 0; --lev) {
+                    auto distribute = [&](int j, int at_level, int8_t& best_a) {
+                        float best = inf;
+                        for (int a = 1; a < j; ++a) {
+                            const float v = cost(k0.ref, at_level, a) + cost(k1.ref, at_level, j - a);
+                            if (v < best) {
+                                best = v;
+                                best_a = (int8_t)a;
+                            }
                         }
-                    }
-                    return best;
-                };
-                int8_t a1 = 1;
-                c[i * (W + 1) + 1] = area(u) + distribute(W, a1);
-                split[i * (W + 1) + 1] = a1;
-                for (int j = 2; j <= W; ++j) {
-                    int8_t aj = 1;
-                    const float dcost = distribute(j, aj);
-                    if (dcost < c[i * (W + 1) + j - 1]) {
-                        c[i * (W + 1) + j] = dcost;
-                        split[i * (W + 1) + j] = aj;
-                    } else {
-                        c[i * (W + 1) + j] = c[i * (W + 1) + j - 1];
-                        split[i * (W + 1) + j] = 0;
+                        return best;
+                    };
+                    int8_t a1 = 1;
+                    c[at(i, lev, 1)] = au + distribute(W, lev + 1, a1); // this binary node becomes a wide node at `lev`
+                    split[at(i, lev, 1)] = a1;
+                    for (int j = 2; j <= W; ++j) {
+                        int8_t aj = 1;
+                        const float dcost = distribute(j, lev, aj); // j roots at this level, over the two subtrees
+                        if (dcost < c[at(i, lev, j - 1)]) {
+                            c[at(i, lev, j)] = dcost;
+                            split[at(i, lev, j)] = aj;
+                        } else {
+                            c[at(i, lev, j)] = c[at(i, lev, j - 1)];
+                            split[at(i, lev, j)] = 0;
+                        }
                     }
                 }
             }
+            if (!(c[at(0, 0, 1)] < inf)) return 0; // (cannot happen for a binary tree of PRT_BVH2_LEVELS levels; the caller falls back)
             struct Emit { int32_t bin; uint32_t slot; uint32_t depth; };
             std::vector<Emit> todo;
             nodes.clear();
@@ -545,19 +561,19 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
             uint32_t wide_depth = 0;
             Kid kids[4];
             int nk = 0;
-            // the roots of the best forest of at most i trees over the binary subtree `k.ref` (box k)
-            auto forest = [&](auto&& self, const Kid& k, int i) -> void {
+            // the roots, at level `lev`, of the best forest of at most i trees over the binary subtree `k.ref` (box k)
+            auto forest = [&](auto&& self, const Kid& k, int lev, int i) -> void {
                 if (k.ref >= 0) {
                     i = std::min(i, W);
-                    while (i > 1 && split[(size_t)k.ref * (W + 1) + i] == 0) --i;
+                    while (i > 1 && split[at((size_t)k.ref, lev, i)] == 0) --i;
                     if (i > 1) {
-                        const int a = split[(size_t)k.ref * (W + 1) + i];
-                        self(self, kid_of(fn[k.ref], 0), a);
-                        self(self, kid_of(fn[k.ref], 1), i - a);
+                        const int a = split[at((size_t)k.ref, lev, i)];
+                        self(self, kid_of(fn[k.ref], 0), lev, a);
+                        self(self, kid_of(fn[k.ref], 1), lev, i - a);
                         return;
                     }
                 }
-                kids[nk++] = k; // a leaf, or a wide node of its own
+                kids[nk++] = k; // a leaf, or a wide node of its own at `lev`
             };
             while (!todo.empty()) {
                 const Emit o = todo.back();
@@ -568,9 +584,9 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
                     kids[nk++] = kid_of(fn[o.bin], 0);
                     kids[nk++] = kid_of(fn[o.bin], 1);
                 } else {
-                    const int a = split[(size_t)o.bin * (W + 1) + 1];
-                    forest(forest, kid_of(fn[o.bin], 0), a);
-                    forest(forest, kid_of(fn[o.bin], 1), W - a);
+                    const int a = split[at((size_t)o.bin, (int)o.depth, 1)];
+                    forest(forest, kid_of(fn[o.bin], 0), (int)o.depth + 1, a);
+                    forest(forest, kid_of(fn[o.bin], 1), (int)o.depth + 1, W - a);
                 }
                 DNode d;
                 for (int i = 0; i < 4; ++i) {
@@ -593,11 +609,16 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
             }
             return wide_depth + 1;
         };
-        out.depth = collapse_optimal(out.nodes);
-        if (tree_stack_need(out.nodes.data(), out.nodes.size()) > PRT_STACK_DEPTH) out.depth = collapse(PRT_STACK_DEPTH, out.nodes);
+        // (the programme's table is 13 x 5 entries per binary node: trees beyond two million nodes keep the greedy rule)
+        const bool dp = fn.size() <= ((size_t)2 << 20);
+        out.depth = dp ? collapse_optimal(PRT_STACK_DEPTH, out.nodes) : 0;
+        if (out.depth == 0 || tree_stack_need(out.nodes.data(), out.nodes.size()) > PRT_STACK_DEPTH) out.depth = collapse(PRT_STACK_DEPTH, out.nodes);
         out.stack_need = tree_stack_need(out.nodes.data(), out.nodes.size());
         out.nodes_shallow.clear();
-        if (out.stack_need > PRT_STACK_SHALLOW) collapse(PRT_STACK_SHALLOW, out.nodes_shallow);
+        if (out.stack_need > PRT_STACK_SHALLOW) {
+            const uint32_t ok = dp ? collapse_optimal(PRT_STACK_SHALLOW, out.nodes_shallow) : 0;
+            if (ok == 0 || tree_stack_need(out.nodes_shallow.data(), out.nodes_shallow.size()) > PRT_STACK_SHALLOW) collapse(PRT_STACK_SHALLOW, out.nodes_shallow);
+        }
     }
     float gm = 0.f; // the dequantised coordinates can exceed the fp32 boxes by one grid step
     for (int a = 0; a < 3; ++a)
