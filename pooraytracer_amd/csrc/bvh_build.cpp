@@ -27,7 +27,7 @@ namespace prt {
 namespace {
 
 #ifndef PRT_SAH_BINS
-#define PRT_SAH_BINS 16
+#define PRT_SAH_BINS 64 // (round 4: 16 -> 64 bins: -1.3 % (cornell), -1.8 % (bathroom2) node visits on random rays, tools/sim_oct8.cpp; the build is not on the hot path)
 #endif
 constexpr int kBins = PRT_SAH_BINS;
 constexpr int kMaxLevels = PRT_BVH2_LEVELS; // inner-node levels of the binary tree
