@@ -203,17 +203,29 @@ struct Builder {
 
 } // namespace
 
-void prim_boxes(const std::vector<HostTri>& tris, std::vector<PrimBox>& out) {
-    // small absolute inflation on top of the outward rounding (the kernel adds its own per-ray pad)
-    double scale = 1.0;
-    for (const HostTri& t : tris)
-        for (int a = 0; a < 3; ++a) scale = std::max(scale, std::max(std::fabs(t.lo[a]), std::fabs(t.hi[a])));
-    const double delta = 1e-9 * scale;
+void prim_boxes(const std::vector<HostTri>& tris, std::vector<PrimBox>& out, float origin[3]) {
+    // Boxes RELATIVE to `origin`, an fp32 point at or below every coordinate (it becomes the grid origin of the 16-bit
+    // nodes; the kernels subtract it from the ray origin in the precision the ray comes in, prt_device.h slab_axis).  The
+    // subtraction happens here in double: the fp32 boxes the builders bin, sort and quantise resolve the scene's EXTENT
+    // to 2^-24, wherever the scene sits in the world — in absolute fp32 coordinates a unit scene at 1e6 had 16 distinct
+    // positions per axis, its SAH tree cost 1.5x the node visits of the same scene at the origin.
+    // A small absolute inflation on top of the outward rounding covers the fp64 roundings of the triangle test, which
+    // scale with the magnitude of the coordinates (the kernel adds its own per-ray pad for the fp32 slab test).
+    double scale = 1.0, lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    for (size_t i = 0; i < tris.size(); ++i)
+        for (int a = 0; a < 3; ++a) {
+            scale = std::max(scale, std::max(std::fabs(tris[i].lo[a]), std::fabs(tris[i].hi[a])));
+            lo[a] = i ? std::min(lo[a], tris[i].lo[a]) : tris[i].lo[a];
+            hi[a] = i ? std::max(hi[a], tris[i].hi[a]) : tris[i].hi[a];
+        }
+    const double extent = std::max(1.0, std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2])));
+    const double delta = 1e-9 * extent + 256.0 * std::numeric_limits<double>::epsilon() * scale;
+    for (int a = 0; a < 3; ++a) origin[a] = round_down(lo[a] - 2.0 * delta);
     out.resize(tris.size());
     for (size_t i = 0; i < tris.size(); ++i)
         for (int a = 0; a < 3; ++a) {
-            out[i].lo[a] = round_down(tris[i].lo[a] - delta);
-            out[i].hi[a] = round_up(tris[i].hi[a] + delta);
+            out[i].lo[a] = round_down((tris[i].lo[a] - delta) - (double)origin[a]); // > 0: the origin lies 2 delta below
+            out[i].hi[a] = round_up((tris[i].hi[a] + delta) - (double)origin[a]);
         }
 }
 
@@ -333,9 +345,10 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
     }
     Builder b(fn);
     b.prims.resize(n);
+    float box_origin[3] = {0.f, 0.f, 0.f}; // every fp32 box below is relative to this point (prim_boxes)
     {
         std::vector<PrimBox> pb;
-        prim_boxes(tris, pb);
+        prim_boxes(tris, pb, box_origin);
         for (size_t i = 0; i < n; ++i) {
             std::memcpy(b.prims[i].lo, pb[i].lo, sizeof(float) * 3);
             std::memcpy(b.prims[i].hi, pb[i].hi, sizeof(float) * 3);
@@ -366,9 +379,9 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
             BuiltBVH::BinNode& o = out.binary[i];
             const float* src[2][3] = {{fn[i].c0x, fn[i].c0y, fn[i].c0z}, {fn[i].c1x, fn[i].c1y, fn[i].c1z}};
             for (int c = 0; c < 2; ++c)
-                for (int a = 0; a < 3; ++a) {
-                    o.lo[c][a] = src[c][a][0];
-                    o.hi[c][a] = src[c][a][1];
+                for (int a = 0; a < 3; ++a) { // (back in world coordinates: the simulator's rays are)
+                    o.lo[c][a] = round_down((double)box_origin[a] + (double)src[c][a][0]);
+                    o.hi[c][a] = round_up((double)box_origin[a] + (double)src[c][a][1]);
                 }
             o.ref[0] = fn[i].ref0;
             o.ref[1] = fn[i].ref1;
@@ -382,11 +395,18 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
     for (size_t i = 0; i < n; ++i) out.order[i] = b.prims[i].idx;
 
     // quantisation grid over the root box: coordinate(q) = g0 + q * gs, evaluated in double here; the
-    // kernel's float evaluation error is covered by its per-ray pad.  lo rounds down, hi rounds up.
+    // kernel's float evaluation error is covered by its per-ray pad.  lo rounds down, hi rounds up.  The boxes are
+    // relative to box_origin, the grid starts there (g0 = 0 in the builder's coordinates), and box_origin is what the
+    // kernels get as the grid origin.
     double g0[3], gs[3];
-    quant_grid(root.lo, root.hi, n == 0, out.grid_origin, out.grid_step);
+    {
+        const float zero[3] = {0.f, 0.f, 0.f};
+        float rel_origin[3];
+        quant_grid(zero, root.hi, n == 0, rel_origin, out.grid_step);
+    }
     for (int a = 0; a < 3; ++a) {
-        g0[a] = out.grid_origin[a];
+        out.grid_origin[a] = box_origin[a];
+        g0[a] = 0.0;
         gs[a] = out.grid_step[a];
     }
     auto qlo = [&](float v, int a) -> uint16_t {
@@ -622,7 +642,7 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
     }
     float gm = 0.f; // the dequantised coordinates can exceed the fp32 boxes by one grid step
     for (int a = 0; a < 3; ++a)
-        gm = std::max(gm, std::max(std::fabs(out.grid_origin[a]), std::fabs((float)(g0[a] + 65535.0 * gs[a]))));
+        gm = std::max(gm, std::fabs((float)(g0[a] + 65535.0 * gs[a])));
     out.coord_scale = std::nextafter(std::max(out.coord_scale, gm), std::numeric_limits<float>::infinity());
     return true;
 }

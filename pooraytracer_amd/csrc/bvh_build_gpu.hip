@@ -455,7 +455,7 @@ void launch_gather_tris(const DTri* tri_in, const DTriShade* shade_in, const uin
         }                                                                               \
     } while (0)
 
-bool build_bvh_device(const PrimBox* h_boxes, size_t n_, DeviceBVH& out, std::string* err) {
+bool build_bvh_device(const PrimBox* h_boxes, const float box_origin[3], size_t n_, DeviceBVH& out, std::string* err) {
     static_assert(sizeof(PrimBox) == sizeof(FBox), "box layouts must agree");
     if (n_ < 2 || n_ >= ((size_t)1 << 28)) {
         if (err) *err = "device BVH build needs 2 <= triangles < 2^28";
@@ -551,8 +551,11 @@ bool build_bvh_device(const PrimBox* h_boxes, size_t n_, DeviceBVH& out, std::st
         if (err) *err = "device BVH build: inconsistent node count";
         return false;
     }
-    Grid g;
-    quant_grid(root_box.lo, root_box.hi, false, g.origin, g.step);
+    Grid g; // in the boxes' own coordinates (relative to box_origin, prim_boxes): the grid starts at 0 there
+    {
+        const float zero[3] = {0.f, 0.f, 0.f};
+        quant_grid(zero, root_box.hi, false, g.origin, g.step);
+    }
     DNode* d_nodes = nullptr;
     uint32_t n_out = 0, out_depth = 0;
     {
@@ -627,7 +630,7 @@ bool build_bvh_device(const PrimBox* h_boxes, size_t n_, DeviceBVH& out, std::st
     out.n_nodes = hs.n_nodes;
     out.depth = hs.depth;
     for (int a = 0; a < 3; ++a) {
-        out.grid_origin[a] = g.origin[a];
+        out.grid_origin[a] = box_origin[a]; // what the kernels subtract from a ray's origin
         out.grid_step[a] = g.step[a];
     }
     float cs = 0.f;
@@ -635,7 +638,7 @@ bool build_bvh_device(const PrimBox* h_boxes, size_t n_, DeviceBVH& out, std::st
     cs = std::nextafter(cs, std::numeric_limits<float>::infinity());
     float gm = 0.f; // the dequantised coordinates can exceed the fp32 boxes by one grid step
     for (int a = 0; a < 3; ++a)
-        gm = std::max(gm, std::max(std::fabs(g.origin[a]), std::fabs((float)((double)g.origin[a] + 65535.0 * (double)g.step[a]))));
+        gm = std::max(gm, std::fabs((float)((double)g.origin[a] + 65535.0 * (double)g.step[a])));
     cs = std::nextafter(std::max(cs, gm), std::numeric_limits<float>::infinity());
     out.coord_scale = cs;
     return true;

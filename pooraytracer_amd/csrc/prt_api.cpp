@@ -466,10 +466,11 @@ static int upload_impl(PrtScene* s, int device) {
     };
     if (s->device_bvh) {
         std::vector<prt::PrimBox> pb;
-        prt::prim_boxes(s->tris, pb);
+        float box_origin[3];
+        prt::prim_boxes(s->tris, pb, box_origin);
         prt::DeviceBVH db;
         std::string err;
-        if (!prt::build_bvh_device(pb.data(), n, db, &err)) return fail(PRT_E_HIP, "prt_scene_upload: " + err);
+        if (!prt::build_bvh_device(pb.data(), box_origin, n, db, &err)) return fail(PRT_E_HIP, "prt_scene_upload: " + err);
         s->allocs.push_back(db.d_nodes);
         d.nodes = db.d_nodes;
         if (dev_env("PRT_VALIDATE_BVH")) { // tests: check the device-built tree on the host before any ray visits it

@@ -28,7 +28,7 @@ struct BuiltBVH {
     int stack_need = 0;          // stack entries a traversal of `nodes` can need at most
     std::vector<uint32_t> order; // BVH leaf order -> index into the HostTri array
     uint32_t depth = 0;
-    float coord_scale = 1.0f;    // >= |every box coordinate|
+    float coord_scale = 1.0f;    // >= |every box coordinate| (relative to grid_origin)
     float grid_origin[3] = {0, 0, 0}, grid_step[3] = {1, 1, 1}; // quantisation grid of the 16-bit boxes
     // tools/sim_oct8.cpp only: the binary SAH tree the wide nodes were collapsed from (pre-order; refs as in DNode)
     struct BinNode {
@@ -39,11 +39,12 @@ struct BuiltBVH {
     std::vector<BinNode> binary;
 };
 
-// fp32 box of one triangle for the BVH builders: HostTri::lo/hi rounded outward + a small absolute inflation
+// fp32 box of one triangle for the BVH builders: HostTri::lo/hi RELATIVE to `origin` (an fp32 point just below every
+// coordinate of the scene, which becomes the grid origin of the 16-bit nodes), rounded outward + a small absolute inflation
 struct PrimBox {
     float lo[3], hi[3];
 };
-void prim_boxes(const std::vector<HostTri>& tris, std::vector<PrimBox>& out);
+void prim_boxes(const std::vector<HostTri>& tris, std::vector<PrimBox>& out, float origin[3]);
 // quantisation grid of the 16-bit boxes over the root box (origin rounds down, 65535 steps reach past hi).
 void quant_grid(const float root_lo[3], const float root_hi[3], bool empty, float origin[3], float step[3]);
 
@@ -86,7 +87,7 @@ bool validate_nodes(const DNode* nodes, size_t n_nodes, size_t n_tris, std::stri
 int tree_stack_need(const DNode* nodes, size_t n_nodes);
 // Same tree family built on the current HIP device from the same fp32 boxes (n >= 2): Morton sort, box
 // segment tree, level-synchronous SAH splits along the Morton order.  Returns false with *err set.
-bool build_bvh_device(const PrimBox* h_boxes, size_t n, DeviceBVH& out, std::string* err);
+bool build_bvh_device(const PrimBox* h_boxes, const float box_origin[3], size_t n, DeviceBVH& out, std::string* err);
 // The reference's lights object graph (main.cpp:36-45, BVH.cpp:7-48) reduced to what
 // BVHNode::Sample/TraverseSample read: per-node left area + children, leaves in CDF order.
 void build_light_tree(const PrtSceneDesc& d, const std::vector<HostTri>& tris, const std::vector<DMaterial>& mats,

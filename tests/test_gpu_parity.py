@@ -495,8 +495,10 @@ def test_scaled_and_translated_scene_hits(gpu, scale, offset):
     check(sc.trace_closest(rays))
     # the device-built tree obeys the same bounds
     check(api.Scene(data, device_bvh=True).upload(gpu).trace_closest(rays))
-    # the box test works relative to the grid origin: where the scene sits in the world does not loosen the culling
-    # (with the pad proportional to the world coordinate a unit scene at 1e6 was not culled at all)
+    # the box test works relative to the grid origin and the builders work on boxes relative to it (prim_boxes): where the
+    # scene sits in the world changes neither the tree nor the culling — the far scene costs the node fetches of the near
+    # one (round 2, pad proportional to the world coordinate: a unit scene at 1e6 was not culled at all; rounds 2-3, fp32
+    # boxes in world coordinates: 16 positions per axis for that scene, 1.5x the fetches)
     if scale < 0.1:  # (a 2e-4 wide scene is mostly the reference's 1e-4 minimum box padding, AABB.cpp:76-82: nothing to cull)
         return
     sc.trace_closest(rays[:20000], count_work=True)
@@ -504,7 +506,7 @@ def test_scaled_and_translated_scene_hits(gpu, scale, offset):
     near = api.Scene(base).upload(gpu)
     r0 = scenes.random_rays(20000, *base.bounds(), seed=31)
     near.trace_closest(r0, count_work=True)
-    assert far <= 1.6 * near.counters()["node_fetches"], (far, near.counters()["node_fetches"])
+    assert far <= 1.02 * near.counters()["node_fetches"], (far, near.counters()["node_fetches"])
 
 
 @pytest.mark.parametrize("dist", [3.0e6, 1.0e9])
