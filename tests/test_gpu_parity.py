@@ -507,6 +507,12 @@ def test_scaled_and_translated_scene_hits(gpu, scale, offset):
     r0 = scenes.random_rays(20000, *base.bounds(), seed=31)
     near.trace_closest(r0, count_work=True)
     assert far <= 1.02 * near.counters()["node_fetches"], (far, near.counters()["node_fetches"])
+    # ... and so does the tree built on the device (Morton codes and SAH bins on the same relative boxes)
+    fd = api.Scene(data, device_bvh=True).upload(gpu)
+    fd.trace_closest(rays[:20000], count_work=True)
+    nd = api.Scene(base, device_bvh=True).upload(gpu)
+    nd.trace_closest(r0, count_work=True)
+    assert fd.counters()["node_fetches"] <= 1.02 * nd.counters()["node_fetches"], (fd.counters()["node_fetches"], nd.counters()["node_fetches"])
 
 
 @pytest.mark.parametrize("dist", [3.0e6, 1.0e9])
