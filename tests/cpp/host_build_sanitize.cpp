@@ -101,16 +101,19 @@ int main() {
     std::mt19937_64 rng(99);
     std::uniform_real_distribution<double> U(0.0, 1.0);
     int n_shallow = 0;
-    for (int round = 0; round < 5; ++round) {
-        const size_t n = round == 0 ? 1 : round == 1 ? 2 : round == 2 ? 37 : round == 3 ? 5000 : 60000;
+    for (int round = 0; round < 7; ++round) {
+        // rounds 5 and 6: the scene far from the world origin (one fp32 ulp there = 1/16 resp. 2 scene units: the builders work on
+        // boxes relative to the grid origin, so the tree invariants below must hold exactly as they do at the origin)
+        const size_t n = round == 0 ? 1 : round == 1 ? 2 : round == 2 ? 37 : round == 3 ? 5000 : round == 4 ? 60000 : 5000;
+        const double off[3] = {round == 5 ? 1.0e6 : round == 6 ? -3.0e7 : 0.0, round == 5 ? -2.0e6 : round == 6 ? 1.0e7 : 0.0, round >= 5 ? 3.0e6 : 0.0};
         std::vector<double> v(n * 9), uv(n * 6), nr(n * 9, 0.0);
         for (size_t t = 0; t < n; ++t) {
             const double cx = U(rng) * 10 - 5, cy = U(rng) * 2, cz = U(rng) * 10 - 5;
             const double s = (t % 97 == 0) ? 3.0 : 0.02 + 0.1 * U(rng); // a few large triangles among small ones
             for (int k = 0; k < 3; ++k) {
-                v[t * 9 + k * 3 + 0] = cx + s * (U(rng) - 0.5);
-                v[t * 9 + k * 3 + 1] = cy + s * (U(rng) - 0.5);
-                v[t * 9 + k * 3 + 2] = cz + s * (U(rng) - 0.5);
+                v[t * 9 + k * 3 + 0] = off[0] + cx + s * (U(rng) - 0.5);
+                v[t * 9 + k * 3 + 1] = off[1] + cy + s * (U(rng) - 0.5);
+                v[t * 9 + k * 3 + 2] = off[2] + cz + s * (U(rng) - 0.5);
                 uv[t * 6 + k * 2] = U(rng);
                 uv[t * 6 + k * 2 + 1] = U(rng);
             }

@@ -85,7 +85,7 @@ def test_host_scene_preparation_under_sanitizers(tmp_path):
                                          os.path.join(csrc, "bvh_build.cpp"), os.path.join(csrc, "scene_setup.cpp"), "-o", exe])
     r = subprocess.run([exe], capture_output=True, env=ENV, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-3000:] + r.stdout.decode()
-    assert r.stdout.decode().count(" ok") == 5
+    assert r.stdout.decode().count(" ok") == 7  # five sizes at the origin + two scenes far from it
 
 
 def test_obj_mtl_xml_loader_survives_corrupted_files(tmp_path):
