@@ -517,7 +517,7 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
         // c(n, i) = min(c(n, i - 1), best split of i roots over the two subtrees).  The builder's leaves stay leaves.  Against
         // the greedy largest-box rule: 20-28 % fewer nodes and, on random rays, -0.9 % (cornell) / -1.9 % (bathroom2) / -9.7 %
         // (veach-mis) node visits (tools/sim_oct8.cpp).  The greedy collapse with its stack budget remains the rule of the 32-entry
-        // tree, of trees beyond two million binary nodes and of the GPU builder.
+        // tree, of trees beyond a million binary nodes and of the GPU builder.
         // The stack bound enters the programme as a LEVEL: a wide node at level L of the wide tree is entered with at most
         // 3 L entries on the stack (every ancestor pushed at most three siblings), so a tree of at most (entries - 1) / 3 levels can
         // never need more than `entries`: c(n, i, L) = least cost of a forest of at most i roots AT LEVEL L over
@@ -629,14 +629,24 @@ bool build_bvh(const std::vector<HostTri>& tris, BuiltBVH& out, std::string* err
             }
             return wide_depth + 1;
         };
-        // (the programme's table is 13 x 5 entries per binary node: trees beyond two million nodes keep the greedy rule)
-        const bool dp = fn.size() <= ((size_t)2 << 20);
-        out.depth = dp ? collapse_optimal(PRT_STACK_DEPTH, out.nodes) : 0;
+        // (the programme's table is 13 x 5 floats + bytes per binary node, 340 MB of transient host memory at a million nodes:
+        // trees beyond that keep the greedy rule, and so does a host that cannot spare the table)
+        bool dp = fn.size() <= ((size_t)1 << 20);
+        auto try_optimal = [&](int entries, std::vector<DNode>& nodes) -> uint32_t {
+            if (!dp) return 0;
+            try {
+                return collapse_optimal(entries, nodes);
+            } catch (const std::bad_alloc&) {
+                dp = false;
+                return 0;
+            }
+        };
+        out.depth = try_optimal(PRT_STACK_DEPTH, out.nodes);
         if (out.depth == 0 || tree_stack_need(out.nodes.data(), out.nodes.size()) > PRT_STACK_DEPTH) out.depth = collapse(PRT_STACK_DEPTH, out.nodes);
         out.stack_need = tree_stack_need(out.nodes.data(), out.nodes.size());
         out.nodes_shallow.clear();
         if (out.stack_need > PRT_STACK_SHALLOW) {
-            const uint32_t ok = dp ? collapse_optimal(PRT_STACK_SHALLOW, out.nodes_shallow) : 0;
+            const uint32_t ok = try_optimal(PRT_STACK_SHALLOW, out.nodes_shallow);
             if (ok == 0 || tree_stack_need(out.nodes_shallow.data(), out.nodes_shallow.size()) > PRT_STACK_SHALLOW) collapse(PRT_STACK_SHALLOW, out.nodes_shallow);
         }
     }
