@@ -395,6 +395,37 @@ def test_update_vertices_matches_fresh_scene(gpu):
 
 
 @pytest.mark.gpu
+def test_update_vertices_rebuilds_the_light_tables(gpu):
+    """Moving EMISSIVE geometry of a scene whose light pick goes through the O(1) tables (veach-mis: four spheres, 6,400 light
+    triangles): areas, CDF order, thresholds and buckets all change with the vertices; the picks after
+    prt_scene_update_vertices are the oracle's picks for the new positions, bit for bit."""
+    import copy
+    data = scenes.veach_mis(width=64, height=36)
+    sc = api.Scene(data).upload(gpu)
+    assert sc.bvh_info()["lds_light_nodes"] < 64  # (tables: only the few nodes above them are staged)
+    v = data.vertices.copy()
+    emissive = [m for m in range(len(data.mesh_material)) if data.materials[int(data.mesh_material[m])].type == _abi.MAT_DIFFUSE_LIGHT]
+    assert len(emissive) >= 2
+    for k, m in enumerate(emissive):
+        sl = slice(int(data.mesh_first_tri[m]), int(data.mesh_first_tri[m + 1]))
+        c = v[sl].reshape(-1, 3).mean(0)
+        v[sl] = (v[sl] - c) * np.array([1.0 + 0.35 * k, 0.8, 1.1 + 0.1 * k]) + c + np.array([0.02 * k, 0.05, -0.03])
+    moved = copy.copy(data)
+    moved.vertices = v
+    sc.update_vertices(v)
+    orc = oracle.Oracle(moved)
+    assert np.array_equal(sc.light_order(), orc.light_order())
+    org = np.random.default_rng(5).uniform(-3, 3, size=(200_000, 3))
+    g, c = sc.sample_lights(org, seed=9), orc.sample_lights(org, seed=9)
+    assert np.array_equal(g["prim"], c["prim"]) and np.array_equal(g["front"], c["front"])
+    assert np.array_equal(g["pdf"].view(np.uint64), c["pdf"].view(np.uint64))
+    assert np.abs(g["position"] - c["position"]).max() <= 1e-13 * max(1.0, np.abs(c["position"]).max())
+    img = sc.render(spp=4, max_depth=8, seed=2)
+    ref, _ = orc.render(spp=4, max_depth=8, seed=2)
+    compare_images(img, ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name,scene_fn,nrays", [
     ("tiny", scenes.tiny_scene, 20_000),
     ("cornell", lambda: scenes.cornell_box(ball_subdiv=4, width=48, height=48), 200_000),
