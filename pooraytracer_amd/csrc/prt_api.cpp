@@ -1051,9 +1051,10 @@ int prt_render_device(PrtScene* s, const PrtCamera* cam, const PrtRenderParams* 
     P.rr = p->russian_roulette;
     P.inv_rr = 1.0 / p->russian_roulette;
     // wave scheduling thresholds (developer overrides through the environment for sweeps)
-    // measured optima at the BASELINE spp with 4-wide nodes (flat within 2 %): lean 28 / 48 / 20, others 20 / 40 / 12
+    // measured optima at the BASELINE spp with 4-wide nodes (flat within 2 %): lean 28 / 48 / 20, others 20 / 40 / 12; the Phong
+    // permutations at three waves: leaf batch 32 (round 4, two sweeps and a four-fold A/B on veach-mis: -0.75 %)
     P.keep = s->feat == 0 ? 28 : 20;
-    P.leaf_batch = s->feat == 0 ? 48 : 40;
+    P.leaf_batch = s->feat == 0 ? 48 : (s->feat & 2) ? 32 : 40; // (2 = Phong, as in s->feat above)
     P.inner_min = s->feat == 0 ? 20 : 12;
     P.cached_min = 24; // measured: veach-mis -1 %, the others flat
     if (const char* e = dev_env("PRT_TUNE_CACHED_MIN")) P.cached_min = std::max(1, std::atoi(e)); // (0 would keep a wave passing for ever)
@@ -1288,7 +1289,7 @@ int prt_render_samples(PrtScene* s, const PrtCamera* cam, const PrtRenderParams*
     P.rr = p->russian_roulette;
     P.inv_rr = 1.0 / p->russian_roulette;
     P.keep = s->feat == 0 ? 28 : 20;
-    P.leaf_batch = s->feat == 0 ? 48 : 40;
+    P.leaf_batch = s->feat == 0 ? 48 : (s->feat & 2) ? 32 : 40; // (2 = Phong, as in s->feat above)
     P.inner_min = s->feat == 0 ? 20 : 12;
     P.scramble = PRT_ITEMS_FROM_LIST;
     P.cached_min = 65;
