@@ -32,9 +32,11 @@ __global__ void k_ray_keys(const PrtRay* __restrict__ rays, uint32_t n, float gx
     const double4* rp = reinterpret_cast<const double4*>(rays + i);
     const double4 r0 = rp[0], r1 = rp[1];
     // cell of the origin in a 512^3 grid over the scene's box (origins outside it go to the boundary cells; NaN -> 0)
-    const float cx = fminf(fmaxf(((float)r0.x - gx) * sx, 0.f), 511.f);
-    const float cy = fminf(fmaxf(((float)r0.y - gy) * sy, 0.f), 511.f);
-    const float cz = fminf(fmaxf(((float)r0.z - gz) * sz, 0.f), 511.f);
+    // (relative to the grid origin in the precision the origin comes in, like the box test: the cells of a scene far from the
+    // world origin are as fine as those of the same scene at the origin)
+    const float cx = fminf(fmaxf((float)(r0.x - (double)gx) * sx, 0.f), 511.f);
+    const float cy = fminf(fmaxf((float)(r0.y - (double)gy) * sy, 0.f), 511.f);
+    const float cz = fminf(fmaxf((float)(r0.z - (double)gz) * sz, 0.f), 511.f);
     const uint32_t m = spread9((uint32_t)cx) | (spread9((uint32_t)cy) << 1) | (spread9((uint32_t)cz) << 2);
     const uint32_t oct = (r1.x < 0.0 ? 1u : 0u) | (r1.y < 0.0 ? 2u : 0u) | (r1.z < 0.0 ? 4u : 0u);
     keys[i] = (m << 3) | oct;
