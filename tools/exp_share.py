@@ -14,7 +14,7 @@ def run(label, reps=3, **kw):
         sc.render_device(None, fb.data_ptr(), max_depth=20, **kw); torch.cuda.synchronize()
         c = sc.counters(); best = min(best, c["kernel_ms"])
     r = c["rays_closest"] + c["rays_shadow"]
-    print(f"{label}: {best:.2f} ms  {r / best / 1e3:.0f} Mrays/s  ideal {r / 8.70e6:.2f} ms  overhead {best - r / 8.70e6:.2f} ms", flush=True)
+    print(f"{label}: {best:.2f} ms  {r / best / 1e3:.0f} Mrays/s  ideal {r / 11.1e6:.2f} ms  overhead {best - r / 11.1e6:.2f} ms", flush=True)
 
 nr = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 for env in ({}, {"PRT_TUNE_VAR": "1"}, {"PRT_TUNE_VAR": "2"}, {"PRT_TUNE_VAR": "4"}, {"PRT_TUNE_VAR": "6"},
